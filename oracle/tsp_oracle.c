@@ -1,0 +1,414 @@
+/*
+ * oracle/tsp_oracle.c -- CPU restatement of the reference's 2-opt hot path.
+ * TEST INFRASTRUCTURE ONLY (see tsp_oracle.h).  Written from the behaviour of
+ * the reference (file:line cited per function), on flat arrays.
+ *
+ * Build: gcc -O2 -ffp-contract=off (x86-64 gcc never fuses a*b+c without -mfma;
+ * the flag makes that explicit so the arithmetic equals the reference's).
+ */
+#define _DEFAULT_SOURCE
+#include "tsp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+#define GEO_PI 3.14159265358979323846264 /* include/distutil.h:6 */
+#define GEO_RADIUS 6378.388              /* include/distutil.h:7 */
+#define GRASP_PICK_BEST 0.9              /* src/heuristics.c:10  */
+
+static double now_s(void) {
+    struct timeval tv;
+    gettimeofday(&tv, 0);
+    return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec;
+}
+
+/* src/distutil.c:4-6 : truncation of x+0.5 through a long */
+static inline double half_up(double v) { return (double)(long)(v + 0.5); }
+
+/* src/distutil.c:51-58 : TSPLIB degrees.minutes -> radians, truncating through a long */
+static inline double geo_radians(double v) {
+    double deg = (double)(long)v;
+    double frac = v - deg;
+    return GEO_PI * (deg + 5.0 * frac / 3.0) / 180.0;
+}
+
+double orc_dist(const double *xy, int i, int j, int wtype, int integer_cost) {
+    const double xi = xy[2 * i], yi = xy[2 * i + 1];
+    const double xj = xy[2 * j], yj = xy[2 * j + 1];
+    switch (wtype) {
+    case ORC_ATT: { /* src/distutil.c:20-31 */
+        double dx = xi - xj, dy = yi - yj;
+        double r = sqrt((dx * dx + dy * dy) / 10.0);
+        if (!integer_cost) return r;
+        double t = half_up(r);
+        return t < r ? t + 1 : t;
+    }
+    case ORC_MAN_2D: { /* src/distutil.c:33-37 ; the y term is (yj - yj), as in the reference */
+        double dx = fabs(xi - xj), dy = fabs(yj - yj);
+        return integer_cost ? half_up(dx + dy) : dx + dy;
+    }
+    case ORC_MAX_2D: { /* src/distutil.c:39-45 ; same y term; dmax = src/utility.c:13-15 */
+        double dx = fabs(xi - xj), dy = fabs(yj - yj);
+        if (integer_cost) { dx = half_up(dx); dy = half_up(dy); }
+        return dx > dy ? dx : dy;
+    }
+    case ORC_CEIL_2D: { /* src/distutil.c:47-49 */
+        double dx = xi - xj, dy = yi - yj;
+        return ceil(sqrt(dx * dx + dy * dy));
+    }
+    case ORC_GEO: { /* src/distutil.c:60-71 */
+        double lat_i = geo_radians(xi), lon_i = geo_radians(yi);
+        double lat_j = geo_radians(xj), lon_j = geo_radians(yj);
+        double q1 = cos(lon_i - lon_j);
+        double q2 = cos(lat_i - lat_j);
+        double q3 = cos(lat_i + lat_j);
+        double d = GEO_RADIUS * acos(0.5 * ((1.0 + q1) * q2 - (1.0 - q1) * q3)) + 1.0;
+        return integer_cost ? half_up(d) : d;
+    }
+    default: { /* EUC_2D and every unknown type: src/distutil.c:13-18, :90-91 */
+        double dx = xi - xj, dy = yi - yj;
+        double d = sqrt(dx * dx + dy * dy);
+        return integer_cost ? half_up(d) : d;
+    }
+    }
+}
+
+void orc_dist_matrix(const double *xy, int n, int wtype, int integer_cost, double *out) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            out[(size_t)i * n + j] = (i == j) ? 0.0 : orc_dist(xy, i, j, wtype, integer_cost);
+}
+
+void orc_srandom(unsigned seed) { srandom(seed); }
+/* include/utility.h:36 */
+double orc_urand(void) { return ((double)random()) / RAND_MAX; }
+
+/* ---- constructive heuristics ------------------------------------------------------------ */
+
+/* src/heuristics.c:18-78 : nearest neighbour, ties -> lowest index (strict <) */
+int orc_greedy(const double *xy, int n, int wtype, int integer_cost, int start, int *succ, double *obj) {
+    if (start >= n) return ORC_WRONG_STARTING_NODE;
+    char *seen = calloc((size_t)n, 1);
+    double total = 0.0;
+    int cur = start;
+    seen[start] = 1;
+    for (;;) {
+        int pick = -1;
+        double pick_d = DBL_MAX;
+        for (int k = 0; k < n; k++) {
+            if (k == cur || seen[k]) continue;
+            double d = orc_dist(xy, cur, k, wtype, integer_cost);
+            if (d < pick_d) { pick_d = d; pick = k; }
+        }
+        if (pick < 0) { succ[cur] = start; break; }
+        succ[cur] = pick;
+        seen[pick] = 1;
+        total += pick_d;
+        cur = pick;
+    }
+    total += orc_dist(xy, cur, start, wtype, integer_cost);
+    *obj = total;
+    free(seen);
+    return ORC_OK;
+}
+
+/* src/heuristics.c:82-156.  Faithful to two quirks of the reference:
+ *  - the runner-up is the previous running minimum of the scan, not the true second nearest
+ *    (:117-122);
+ *  - the closing edge is added inside the loop (:135) and again after it (:152). */
+int orc_grasp(const double *xy, int n, int wtype, int integer_cost, int start, const double *urand,
+              int *succ, double *obj) {
+    if (start >= n) return ORC_WRONG_STARTING_NODE;
+    char *seen = calloc((size_t)n, 1);
+    double total = 0.0;
+    int cur = start;
+    int draw = 0;
+    seen[start] = 1;
+    for (;;) {
+        int best = -1, runner = -1;
+        double best_d = DBL_MAX, runner_d = DBL_MAX;
+        for (int k = 0; k < n; k++) {
+            if (k == cur || seen[k]) continue;
+            double d = orc_dist(xy, cur, k, wtype, integer_cost);
+            if (d < best_d) {
+                runner_d = best_d; runner = best;
+                best_d = d; best = k;
+            }
+        }
+        double u = urand ? urand[draw] : orc_urand();
+        draw++;
+        int pick = (u < GRASP_PICK_BEST || best == -1 || runner == -1) ? best : runner;
+        if (pick == -1) {
+            succ[cur] = start;
+            total += orc_dist(xy, cur, start, wtype, integer_cost);
+            break;
+        }
+        double pick_d = (pick == best) ? best_d : runner_d;
+        succ[cur] = pick;
+        seen[pick] = 1;
+        total += pick_d;
+        cur = pick;
+    }
+    total += orc_dist(xy, cur, start, wtype, integer_cost);
+    *obj = total;
+    free(seen);
+    return ORC_OK;
+}
+
+/* src/heuristics.c:168-205 */
+int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj) {
+    int *trial = malloc(sizeof(int) * (size_t)n);
+    double best = DBL_MAX;
+    memset(succ, 0, sizeof(int) * (size_t)n);
+    for (int s = 0; s < n; s++) {
+        double c;
+        orc_greedy(xy, n, wtype, integer_cost, s, trial, &c);
+        if (c < best) { best = c; memcpy(succ, trial, sizeof(int) * (size_t)n); }
+    }
+    *obj = best;
+    free(trial);
+    return ORC_OK;
+}
+
+/* ---- 2-opt ----------------------------------------------------------------------------- */
+
+static void rebuild_prev(int n, const int *succ, int *prev) {
+    for (int k = 0; k < n; k++) prev[succ[k]] = k;
+}
+
+/* src/utility.c:708-722 : walk backwards from start_node to end_node flipping successors,
+ * then rebuild every predecessor (the reference pays that O(n) on each move). */
+static long long reverse_walk(int n, int *succ, int start_node, int end_node, int *prev) {
+    long long touched = 0;
+    int cur = start_node;
+    for (;;) {
+        int p = prev[cur];
+        succ[cur] = p;
+        touched++;
+        cur = p;
+        if (p == end_node) break;
+    }
+    rebuild_prev(n, succ, prev);
+    return touched;
+}
+
+void orc_reverse_path(int n, int *succ, int start_node, int end_node, int *prev) {
+    (void)reverse_walk(n, succ, start_node, end_node, prev);
+}
+
+/* src/heuristics.c:438-502 */
+int orc_two_opt_first(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                      double time_limit, int clock_per_pair, orc_stats *st, orc_move *trace,
+                      long long trace_cap) {
+    const double t0 = now_s();
+    orc_stats s = {0, 0, 0, 0, 0.0};
+    int status = ORC_OK;
+    int *prev = malloc(sizeof(int) * (size_t)n);
+    for (int k = 0; k < n; k++) prev[k] = -1;
+    rebuild_prev(n, succ, prev);
+    double seen_cost = *obj;
+    double cost = *obj;
+
+    for (;;) {
+        for (int i = 0; i < n - 1 && status == ORC_OK; i++) {
+            if (!clock_per_pair && time_limit > 0 && now_s() - t0 > time_limit) {
+                status = ORC_TIME_LIMIT_EXCEEDED;
+                break;
+            }
+            for (int j = i + 1; j < n; j++) {
+                if (clock_per_pair) { /* src/heuristics.c:456-462 */
+                    double el = now_s() - t0;
+                    if (time_limit > 0 && el > time_limit) { status = ORC_TIME_LIMIT_EXCEEDED; break; }
+                }
+                const int i_next = succ[i], j_next = succ[j];
+                if (i_next == j_next || i == j_next || j == i_next) continue; /* :471 */
+                s.evals++;
+                double delta = orc_dist(xy, i, j, wtype, integer_cost)
+                             + orc_dist(xy, i_next, j_next, wtype, integer_cost)
+                             - orc_dist(xy, i, i_next, wtype, integer_cost)
+                             - orc_dist(xy, j, j_next, wtype, integer_cost); /* :474 */
+                if (delta < 0) {
+                    succ[i] = j;
+                    succ[i_next] = j_next;
+                    s.reversed += reverse_walk(n, succ, j, i_next, prev);
+                    cost += delta;
+                    if (trace && s.moves < trace_cap) {
+                        trace[s.moves].i = i; trace[s.moves].j = j; trace[s.moves].delta = delta;
+                    }
+                    s.moves++;
+                }
+            }
+        }
+        s.sweeps++;
+        if (cost >= seen_cost) break; /* :492 */
+        seen_cost = cost;
+    }
+    *obj = cost;
+    free(prev);
+    s.seconds = now_s() - t0;
+    if (st) *st = s;
+    return status;
+}
+
+/* src/utility.c:17-30 */
+int orc_udir_pos(int i, int j, int n) {
+    if (i > j) { int t = i; i = j; j = t; }
+    return i * n + j - ((i + 1) * (i + 2)) / 2;
+}
+
+/* src/tabusearch.c:83-92 : lazily clears an expired stamp */
+static int stamp_is_tabu(int *stamp, int iter, int tenure) {
+    if (iter < 0 || tenure < 0) return 0;
+    if (*stamp == 0) return 0;
+    if (iter - *stamp > tenure) { *stamp = 0; return 0; }
+    return 1;
+}
+
+/* src/tabusearch.c:107-178 */
+int orc_two_opt_best(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                     int *tabu, int iter, int tenure, int *stored_prev, double time_limit,
+                     long long max_sweeps, orc_stats *st, orc_move *trace, long long trace_cap) {
+    const double t0 = now_s();
+    orc_stats s = {0, 0, 0, 0, 0.0};
+    int status = ORC_OK;
+    int *prev = malloc(sizeof(int) * (size_t)n);
+    for (int k = 0; k < n; k++) prev[k] = -1;
+    rebuild_prev(n, succ, prev);
+    int arg_i = 0, arg_j = 0;
+
+    for (;;) {
+        if (time_limit > 0 && now_s() - t0 > time_limit) { status = ORC_TIME_LIMIT_EXCEEDED; break; }
+        if (max_sweeps >= 0 && s.sweeps >= max_sweeps) break;
+        double low = 0.0;
+        for (int i = 0; i < n - 1; i++) {
+            for (int j = i + 1; j < n; j++) {
+                const int i_next = succ[i], j_next = succ[j];
+                if (j == i_next || j_next == i) continue; /* :134 */
+                if (tabu &&
+                    (stamp_is_tabu(&tabu[orc_udir_pos(i, j, n)], iter, tenure) ||
+                     stamp_is_tabu(&tabu[orc_udir_pos(i, i_next, n)], iter, tenure) ||
+                     stamp_is_tabu(&tabu[orc_udir_pos(j, j_next, n)], iter, tenure) ||
+                     stamp_is_tabu(&tabu[orc_udir_pos(i, j_next, n)], iter, tenure)))
+                    continue; /* :137-149 */
+                s.evals++;
+                double delta = orc_dist(xy, i, j, wtype, integer_cost)
+                             + orc_dist(xy, i_next, j_next, wtype, integer_cost)
+                             - orc_dist(xy, i, i_next, wtype, integer_cost)
+                             - orc_dist(xy, j, j_next, wtype, integer_cost); /* :150 */
+                if (delta < low) { low = delta; arg_i = i; arg_j = j; }
+            }
+        }
+        s.sweeps++;
+        if (low >= 0) break; /* :158 */
+        const int i_next = succ[arg_i], j_next = succ[arg_j];
+        succ[arg_i] = arg_j;
+        succ[i_next] = j_next;
+        s.reversed += reverse_walk(n, succ, arg_j, i_next, prev);
+        if (trace && s.moves < trace_cap) {
+            trace[s.moves].i = arg_i; trace[s.moves].j = arg_j; trace[s.moves].delta = low;
+        }
+        s.moves++;
+    }
+    *obj = orc_succ_cost(xy, n, wtype, integer_cost, succ); /* :168-172 */
+    if (stored_prev) memcpy(stored_prev, prev, sizeof(int) * (size_t)n);
+    free(prev);
+    s.seconds = now_s() - t0;
+    if (st) *st = s;
+    return status;
+}
+
+/* ---- tour cost / representation -------------------------------------------------------- */
+
+/* src/genetic.c:51-60 */
+double orc_perm_cost(const double *xy, int n, int wtype, int integer_cost, const int *perm) {
+    double c = 0.0;
+    int last = perm[0];
+    for (int k = 1; k < n; k++) {
+        c += orc_dist(xy, last, perm[k], wtype, integer_cost);
+        last = perm[k];
+    }
+    c += orc_dist(xy, last, perm[0], wtype, integer_cost);
+    return c;
+}
+
+/* src/tabusearch.c:168-172 */
+double orc_succ_cost(const double *xy, int n, int wtype, int integer_cost, const int *succ) {
+    double c = 0.0;
+    for (int k = 0; k < n; k++) c += orc_dist(xy, k, succ[k], wtype, integer_cost);
+    return c;
+}
+
+/* src/genetic.c:33-42 */
+void orc_perm_to_succ(int n, const int *perm, int *succ) {
+    for (int k = 0; k + 1 < n; k++) succ[perm[k]] = perm[k + 1];
+    succ[perm[n - 1]] = perm[0];
+}
+
+/* src/genetic.c:436-441 : walk from node 0 */
+void orc_succ_to_perm(int n, const int *succ, int *perm) {
+    int v = 0;
+    for (int k = 0; k < n; k++) { perm[k] = v; v = succ[v]; }
+}
+
+/* src/genetic.c:349-364 with rand_choice = src/utility.c:752-753 */
+void orc_random_perm(int n, int *perm) {
+    for (int k = 0; k < n; k++) perm[k] = k;
+    for (int k = 0; k < n; k++) {
+        int p = (int)(orc_urand() * n);
+        int q = (int)(orc_urand() * n);
+        int t = perm[p]; perm[p] = perm[q]; perm[q] = t;
+    }
+}
+
+/* ---- TSPLIB reader (src/utility.c:351-453) -------------------------------------------- */
+
+int orc_parse_tsplib(const char *path, double *xy, int cap, int *wtype) {
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    char line[256];
+    const char *sep = " :\n\t\r";
+    int n = -1, in_coords = 0, wt = -1;
+    while (fgets(line, sizeof line, fp)) {
+        char *key = strtok(line, sep);
+        if (!key) continue;
+        if (!strncmp(key, "EOF", 3)) break;
+        if (!strncmp(key, "DIMENSION", 9)) { char *v = strtok(NULL, sep); n = v ? atoi(v) : -1; in_coords = 0; continue; }
+        if (!strncmp(key, "EDGE_WEIGHT_TYPE", 16)) {
+            char *v = strtok(NULL, sep);
+            if (v) {
+                if (!strncmp(v, "EUC_2D", 6)) wt = ORC_EUC_2D;
+                if (!strncmp(v, "MAX_2D", 6)) wt = ORC_MAX_2D;
+                if (!strncmp(v, "MAN_2D", 6)) wt = ORC_MAN_2D;
+                if (!strncmp(v, "CEIL_2D", 7)) wt = ORC_CEIL_2D;
+                if (!strncmp(v, "GEO", 3)) wt = ORC_GEO;
+                if (!strncmp(v, "ATT", 3)) wt = ORC_ATT;
+                if (!strncmp(v, "EXPLICIT", 8)) { fclose(fp); return -3; }
+            }
+            in_coords = 0;
+            continue;
+        }
+        if (!strncmp(key, "NODE_COORD_SECTION", 18)) { in_coords = 1; continue; }
+        if (!strncmp(key, "NAME", 4) || !strncmp(key, "COMMENT", 7) || !strncmp(key, "TYPE", 4) ||
+            !strncmp(key, "EDGE_WEIGHT_SECTION", 19)) { in_coords = 0; continue; }
+        if (in_coords) {
+            int id = atoi(key) - 1;
+            if (n < 0 || id < 0 || id >= n) { fclose(fp); return -2; }
+            char *a = strtok(NULL, sep), *b = strtok(NULL, sep);
+            if (xy && id < cap && a && b) { xy[2 * id] = atof(a); xy[2 * id + 1] = atof(b); }
+        }
+    }
+    fclose(fp);
+    if (wtype) *wtype = wt;
+    return n > 0 ? n : -2;
+}
+
+unsigned long long orc_fnv1a(const int *v, int n) {
+    unsigned long long h = 1469598103934665603ULL;
+    const unsigned char *p = (const unsigned char *)v;
+    for (size_t k = 0; k < sizeof(int) * (size_t)n; k++) { h ^= p[k]; h *= 1099511628211ULL; }
+    return h;
+}

@@ -1,0 +1,106 @@
+/*
+ * oracle/tsp_oracle.h -- CPU restatement of the reference's 2-opt hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (tsp_optimization_amd/,
+ * include/, the C-ABI library, the host mirror, the CLI) may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / the timed CPU comparator.
+ *
+ * Parity status: PINNED against the reference's own published known answers
+ * (results/constructive_heuristics_new.csv and
+ * results/constructive_heuristics_2opt_new.csv, seed 123; committed as
+ * tests/golden/reference_results.json) and against the counters SURVEY.md
+ * Appendix B recorded from the unmodified reference.  The reference itself is
+ * NOT buildable in this image (every source includes <cplex.h>, which the image
+ * lacks, and stand-in headers are not allowed), so there is no oracle/_ref.
+ *
+ * Every function cites the reference file:line whose behaviour it restates.
+ * Data is passed as flat arrays (xy = n x {x,y} doubles, succ = successor list)
+ * rather than the reference's `instance` struct.
+ */
+#ifndef TSP_ORACLE_H
+#define TSP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* weight types, numbered like the reference's enum (include/utility.h:45-52) */
+enum { ORC_EUC_2D = 0, ORC_MAX_2D = 1, ORC_MAN_2D = 2, ORC_CEIL_2D = 3, ORC_GEO = 4, ORC_ATT = 5 };
+
+/* status codes (include/heuristics.h:6-7) */
+enum { ORC_OK = 0, ORC_WRONG_STARTING_NODE = 1, ORC_TIME_LIMIT_EXCEEDED = 2 };
+
+typedef struct {
+    long long sweeps;      /* completed passes over the (i<j) pair space            */
+    long long evals;       /* executions of the delta expression (non-skipped pairs) */
+    long long moves;       /* applied 2-opt moves (= reverse_path calls)            */
+    long long reversed;    /* nodes whose successor was rewritten by reversals      */
+    double seconds;        /* wall time of the call                                  */
+} orc_stats;
+
+typedef struct {           /* one applied move, for trajectory parity */
+    int i, j;
+    double delta;
+} orc_move;
+
+/* src/distutil.c:73-92 (+ :4-71) */
+double orc_dist(const double *xy, int i, int j, int wtype, int integer_cost);
+
+/* Fill an n x n row-major matrix with orc_dist(i,j); diagonal = 0. */
+void orc_dist_matrix(const double *xy, int n, int wtype, int integer_cost, double *out);
+
+/* src/heuristics.c:18-78 */
+int orc_greedy(const double *xy, int n, int wtype, int integer_cost, int start, int *succ, double *obj);
+
+/* src/heuristics.c:82-156; draws from libc random() exactly like URAND() (include/utility.h:36).
+ * If urand != NULL the n draws are taken from urand[0..n-1] instead (same values, no libc state). */
+int orc_grasp(const double *xy, int n, int wtype, int integer_cost, int start, const double *urand,
+              int *succ, double *obj);
+
+/* src/heuristics.c:168-205 (all n starting nodes, keep the best) */
+int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj);
+
+/* src/heuristics.c:438-502 (first improvement, moves applied immediately).
+ * clock_per_pair != 0 also calls gettimeofday once per pair as the reference does (:456). */
+int orc_two_opt_first(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                      double time_limit, int clock_per_pair, orc_stats *st, orc_move *trace,
+                      long long trace_cap);
+
+/* src/tabusearch.c:107-178 (best improvement; tabu == NULL gives plain best-improvement 2-opt).
+ * max_sweeps < 0 = until local optimum (max_sweeps is a harness knob for bounded timing samples). */
+int orc_two_opt_best(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                     int *tabu, int iter, int tenure, int *stored_prev, double time_limit,
+                     long long max_sweeps, orc_stats *st, orc_move *trace, long long trace_cap);
+
+/* src/utility.c:708-722 */
+void orc_reverse_path(int n, int *succ, int start_node, int end_node, int *prev);
+
+/* src/genetic.c:51-60 : cost of a permutation */
+double orc_perm_cost(const double *xy, int n, int wtype, int integer_cost, const int *perm);
+/* src/tabusearch.c:168-172 : cost of a successor list, summed in node order */
+double orc_succ_cost(const double *xy, int n, int wtype, int integer_cost, const int *succ);
+/* src/genetic.c:33-42 and :436-441 */
+void orc_perm_to_succ(int n, const int *perm, int *succ);
+void orc_succ_to_perm(int n, const int *succ, int *perm);
+/* src/genetic.c:349-364, libc random() via rand_choice (src/utility.c:752) */
+void orc_random_perm(int n, int *perm);
+
+/* src/utility.c:17-30 */
+int orc_udir_pos(int i, int j, int n);
+
+/* libc RNG access so that tests can reproduce the reference's stream (src/solver.c:264-266) */
+void orc_srandom(unsigned seed);
+double orc_urand(void);
+
+/* src/utility.c:351-453 : TSPLIB NODE_COORD reader.  Returns n (>0) or a negative error.
+ * xy may be NULL to query n only; cap = capacity of xy in nodes. */
+int orc_parse_tsplib(const char *path, double *xy, int cap, int *wtype);
+
+/* 64-bit FNV-1a over the n ints of a successor list (fixture compaction helper) */
+unsigned long long orc_fnv1a(const int *v, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Regenerates the fixtures under tests/golden/ (run in the build container only).
+
+Three kinds of fixture, kept apart on purpose:
+
+1. reference_results.json  -- cells of the reference's OWN published result tables
+   (/root/reference/results/constructive_heuristics_new.csv and
+   constructive_heuristics_2opt_new.csv, produced by other_codes/constructive_comparison.py
+   with `-seed 123`).  Only the deterministic, in-scope columns are kept.  These pin the oracle.
+2. survey_appendix_b.json  -- counters (sweeps / delta evaluations / moves) and costs that
+   SURVEY.md Appendix B recorded from the unmodified reference (gcov counts).  Transcribed by
+   hand from SURVEY.md; they pin the oracle's trajectory, not only its final cost.
+3. oracle_vectors.json     -- vectors produced by oracle/ (after 1 and 2 pass) on seeded inputs:
+   successor-list hashes, move traces, the att532 x 256 multistart table.  They are regression
+   vectors for the HIP path and are only as good as the oracle pinned by 1 and 2.
+
+instances/*.tsp are TSPLIB data files copied from /root/reference/data (data, not source).
+"""
+import csv
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+REF = "/root/reference/results"
+INST = os.path.join(HERE, "instances")
+
+
+def reference_results():
+    keep = {"constructive_heuristics_new.csv": ["GREEDY", "GREEDY_ITER", "GRASP"],
+            "constructive_heuristics_2opt_new.csv": ["2OPT_GREEDY", "2OPT_GREEDY_ITER"]}
+    out = {"_source": "deno750/TSP_Optimization results/*.csv, -seed 123; see make_golden.py",
+           "_dropped": "EXTR_MILE/2OPT_EXTR_MIL (out of scope), 2OPT_GRASP (stale revision, "
+                       "SURVEY.md section 4), *_GRASP_ITER (wall-clock bound)",
+           "instances": {}}
+    for fn, cols in keep.items():
+        with open(os.path.join(REF, fn)) as f:
+            for row in csv.DictReader(f):
+                path = row[next(iter(row))]  # first column: ../data/heuristics/<name>.tsp
+                name = os.path.basename(path)[:-4]
+                d = out["instances"].setdefault(name, {})
+                for c in cols:
+                    d[c] = float(row[c])
+    return out
+
+
+def survey_appendix_b():
+    # SURVEY.md Appendix B / section 6, transcribed.  sw=sweeps, ev=delta evaluations, mv=moves.
+    return {
+        "_source": "SURVEY.md Appendix B (gcov counts of heuristics.c:474,483,492 / tabusearch.c:150,165 "
+                   "on the unmodified reference)",
+        "berlin52": {"greedy": 8980, "first": {"cost": 8083, "sw": 5, "ev": 6380, "mv": 20, "reversed": 702},
+                     "best": {"cost": 7842, "sw": 12, "ev": 15288, "mv": 11},
+                     "grasp123": {"reported": 10001, "true": 9360},
+                     "first_from_grasp123": {"reported": 8746, "true": 8105},
+                     "greedy_iter": 8181, "first_from_greedy_iter": 7837},
+        "pr299": {"greedy": 59890, "first": {"cost": 51436, "sw": 5, "ev": 221286, "mv": 75},
+                  "best": {"cost": 50666, "sw": 52, "ev": 2301104, "mv": 51},
+                  "grasp123": {"reported": 77865}, "first_from_grasp123": {"reported": 54064}},
+        "att532": {"greedy": 35516, "first": {"cost": 30594, "sw": 7, "ev": 985083, "mv": 237},
+                   "best": {"cost": 29037, "sw": 99, "ev": 13930686, "mv": 98},
+                   "grasp123": {"reported": 42259},
+                   "first_from_grasp123": {"reported": 31988, "sw": 6, "ev": 844387, "mv": 295},
+                   "greedy_iter": 33387, "first_from_greedy_iter": 29836,
+                   "multistart256": {"start0": {"node": 31, "grasp_reported": 42216, "grasp_true": 39693,
+                                                "opt_reported": 33208, "opt_true": 30685},
+                                     "start1": {"node": 318, "grasp_reported": 41777, "grasp_true": 40893,
+                                                "opt_reported": 31317, "opt_true": 30433},
+                                     "best_true": 28998, "best_start": 122}},
+        "rand1000": {"greedy": 29062445, "first": {"cost": 24665416, "sw": 5, "ev": 2492615, "mv": 318},
+                     "best": {"cost": 24067579, "sw": 163, "ev": 81255500, "mv": 162}},
+        "rand2000": {"greedy": 40193021, "first": {"cost": 35367870},
+                     "best": {"cost": 34329138, "sw": 287, "ev": 573139000, "mv": 286}},
+        "rand5000": {"greedy": 64152006, "first": {"cost": 55034087, "sw": 7, "ev": 87448026, "mv": 1449}},
+        "rand10000": {"greedy": 88104308, "first": {"cost": 77370387, "sw": 10, "ev": 499850987, "mv": 2704}},
+    }
+
+
+def rand_instance(n):
+    """uniform integer coordinates, numpy PCG64 seeded with n."""
+    return np.random.default_rng(n).integers(0, 1_000_000, size=(n, 2)).astype(np.float64)
+
+
+def load(name):
+    if name.startswith("rand"):
+        return rand_instance(int(name[4:])), O.EUC_2D
+    return O.parse_tsplib(os.path.join(INST, name + ".tsp"))
+
+
+def oracle_vectors():
+    out = {"_source": "oracle/tsp_oracle.c via tests/golden/make_golden.py", "cases": {}}
+    for name in ["berlin52", "pr299", "att532", "d493", "rand1000", "rand2000"]:
+        xy, wt = load(name)
+        _, g_succ, g_obj = O.greedy(xy, wt)
+        case = {"n": len(xy), "wtype": wt, "xy_sum": float(xy.sum()),
+                "greedy": {"obj": g_obj, "hash": O.fnv1a(g_succ)}}
+        _, s1, o1, st1, tr1 = O.two_opt_first(xy, wt, g_succ, g_obj, trace_cap=4096)
+        st1.pop("seconds")
+        case["first"] = {"obj": o1, "hash": O.fnv1a(s1), "stats": st1, "trace": tr1[:96]}
+        if len(xy) <= 1000:
+            _, s2, o2, st2, tr2, _ = O.two_opt_best(xy, wt, g_succ, trace_cap=4096)
+            st2.pop("seconds")
+            case["best"] = {"obj": o2, "hash": O.fnv1a(s2), "stats": st2, "trace": tr2[:96]}
+        O.srandom(123)
+        _, r_succ, r_obj = O.grasp(xy, wt)
+        _, s3, o3, st3, _ = O.two_opt_first(xy, wt, r_succ, r_obj)
+        st3.pop("seconds")
+        case["grasp123"] = {"obj": r_obj, "true": O.succ_cost(xy, wt, r_succ), "hash": O.fnv1a(r_succ)}
+        case["first_from_grasp123"] = {"obj": o3, "true": O.succ_cost(xy, wt, s3), "hash": O.fnv1a(s3),
+                                       "stats": st3}
+        out["cases"][name] = case
+
+    # att532, 256 GRASP starts, stream order of heuristics.c:519 then :127
+    xy, wt = load("att532")
+    n = len(xy)
+    O.srandom(123)
+    table = []
+    for k in range(256):
+        node = int(O.urand() * (n - 1))
+        _, succ, obj = O.grasp(xy, wt, start=node)
+        true0 = O.succ_cost(xy, wt, succ)
+        _, s2, o2, st, _ = O.two_opt_first(xy, wt, succ, obj)
+        table.append({"k": k, "node": node, "grasp_reported": obj, "grasp_true": true0,
+                      "opt_reported": o2, "opt_true": O.succ_cost(xy, wt, s2),
+                      "hash": O.fnv1a(s2), "ev": st["evals"], "mv": st["moves"], "sw": st["sweeps"]})
+    out["att532_multistart256"] = table
+    return out
+
+
+def main():
+    for fn, fun in [("reference_results.json", reference_results),
+                    ("survey_appendix_b.json", survey_appendix_b),
+                    ("oracle_vectors.json", oracle_vectors)]:
+        with open(os.path.join(HERE, fn), "w") as f:
+            json.dump(fun(), f, indent=1, sort_keys=True)
+        print("wrote", fn)
+
+
+if __name__ == "__main__":
+    main()
