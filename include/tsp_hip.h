@@ -1,0 +1,177 @@
+/*
+ * include/tsp_hip.h -- C ABI of libtsp_hip.so, the MI355X (gfx950) 2-opt local-search engine.
+ *
+ * This is the drop-in boundary for the heuristics path of deno750/TSP_Optimization.  The
+ * reference has no FFI layer; the seam is the set of C functions that its solver dispatch and
+ * meta-heuristics call.  Each entry point below names the reference
+ * function whose body it replaces.  Host code stays C: it keeps the reference's `instance`
+ * struct and calls these functions with the struct's own arrays (see INTEGRATION.md and
+ * tsp_optimization_amd/host/).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Return value: 0 = ok, 1 = WRONG_STARTING_NODE, 2 = TIME_LIMIT_EXCEEDED (the reference's
+ *     include/heuristics.h:6-7); negative = TSP_DEV_E_* (the reference has no such class: its
+ *     unrecoverable errors go through LOG_E -> exit(1), include/utility.h:33).
+ *   - `xy` is the reference's `point` array: n x {double x, double y} (include/utility.h:126-129),
+ *     so `(const double *)inst->nodes` can be passed as is.
+ *   - Tours are successor lists.  `succ` + `succ_stride` (in ints) address them: stride 1 for a
+ *     plain int array, stride 2 with succ = &inst->solution.edges[0].j for the reference's
+ *     `edge {int i; int j;}` array (include/utility.h:134-137).  Batched tours are
+ *     `tour_stride` ints apart.
+ *   - Weight types are numbered like the reference's enum weight_type (include/utility.h:45-52).
+ *   - Nothing here falls back to the CPU: without a usable HIP device every call fails with
+ *     TSP_DEV_E_NODEVICE.
+ */
+#ifndef TSP_HIP_H
+#define TSP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* weight types: include/utility.h:45-52 */
+enum { TSP_EUC_2D = 0, TSP_MAX_2D = 1, TSP_MAN_2D = 2, TSP_CEIL_2D = 3, TSP_GEO = 4, TSP_ATT = 5 };
+
+/* status codes */
+enum {
+    TSP_OK = 0,
+    TSP_WRONG_STARTING_NODE = 1,  /* include/heuristics.h:6 */
+    TSP_TIME_LIMIT_EXCEEDED = 2,  /* include/heuristics.h:7 */
+    TSP_DEV_E_NODEVICE = -1,      /* no HIP device / HIP runtime error at init */
+    TSP_DEV_E_HIP = -2,           /* a HIP call failed (tsp_dev_last_error() has the text) */
+    TSP_DEV_E_ARG = -3,           /* bad argument (NULL, n < 4, unknown mode ...) */
+    TSP_DEV_E_NOT_A_TOUR = -4,    /* a successor list is not one Hamiltonian cycle */
+    TSP_DEV_E_NOMEM = -5
+};
+
+/* 2-opt move selection */
+enum {
+    TSP_2OPT_FIRST = 0, /* alg_2opt: first improvement in (i<j) node order, applied immediately
+                           (src/heuristics.c:438-502) */
+    TSP_2OPT_BEST = 1   /* alg_2opt_tabu: best improvement, ties -> first pair (src/tabusearch.c:107-178) */
+};
+
+/* constructive heuristics */
+enum {
+    TSP_CONSTRUCT_GREEDY = 0, /* greedy(): src/heuristics.c:18-78 */
+    TSP_CONSTRUCT_GRASP = 1   /* grasp():  src/heuristics.c:82-156 */
+};
+
+/* 2-opt execution engine (a performance choice; results are identical) */
+enum {
+    TSP_ENGINE_AUTO = 0,
+    TSP_ENGINE_GRID = 1, /* many workgroups per tour, tour state in HBM, one launch pair per step */
+    TSP_ENGINE_LDS = 2   /* one workgroup per tour, whole descent inside one launch, state in LDS */
+};
+
+typedef struct tsp_dev_ctx tsp_dev_ctx;     /* one device + stream */
+typedef struct tsp_dev_inst tsp_dev_inst;   /* node coordinates resident in HBM */
+typedef struct tsp_dev_tours tsp_dev_tours; /* B tours of one instance resident in HBM */
+typedef struct tsp_dev_tabu tsp_dev_tabu;   /* n(n-1)/2 tabu stamps resident in HBM */
+
+typedef struct {
+    int64_t sweeps;        /* completed passes over the (i<j) pair space                         */
+    int64_t evals;         /* delta evaluations the reference would have executed (non-skipped
+                              pairs, src/heuristics.c:474 / src/tabusearch.c:150)                */
+    int64_t moves;         /* applied 2-opt moves                                                */
+    int64_t reversed;      /* tour positions rewritten by segment reversals                      */
+    int64_t pairs_scanned; /* pairs the device actually evaluated (>= evals in FIRST mode: a
+                              chunk is scanned past the first improving pair)                    */
+    int64_t steps;         /* scan+apply launch pairs (GRID) or chunk iterations (LDS)           */
+    double seconds;        /* wall time of the call, host clock                                  */
+    double device_ms;      /* device time of the call, HIP events on the engine's stream         */
+} tsp_two_opt_stats;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Opens device `device` (hipSetDevice) and creates the engine's stream. */
+int tsp_dev_open(int device, tsp_dev_ctx **out);
+void tsp_dev_close(tsp_dev_ctx *ctx);
+/* Text of the last failing HIP call on this thread ("" if none). */
+const char *tsp_dev_last_error(void);
+/* Number of HIP devices visible (0 if none / no runtime).  Does not create a context. */
+int tsp_dev_count(void);
+int tsp_dev_synchronize(tsp_dev_ctx *ctx);
+/* The hipStream_t the engine launches on (as void*), for callers that order work against it. */
+void *tsp_dev_stream(tsp_dev_ctx *ctx);
+
+/* ---- instance: replaces the operand side of calc_dist (src/distutil.c:73-92) -------------- */
+
+int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_type,
+                        int integer_cost, tsp_dev_inst **out);
+void tsp_dev_inst_destroy(tsp_dev_inst *inst);
+int tsp_dev_inst_size(const tsp_dev_inst *inst);
+
+/* calc_dist(i,j) for `count` index pairs, evaluated on the device (parity / spot checks). */
+int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count, double *out);
+
+/* Full n x n matrix of calc_dist (row-major, diagonal 0) -- the north star's "distance-matrix
+ * build"; the reference recomputes distances on every call and has no such array.
+ * out_host may be NULL (timing only).  Elements are int32 when as_int32 != 0 (valid only with
+ * integer costs), else double.  *kernel_ms receives the kernel's device time if not NULL. */
+int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float *kernel_ms);
+
+/* ---- construction: greedy() / grasp() for B starting nodes at once ------------------------ */
+/* kind = TSP_CONSTRUCT_*.  starts[B].  urand: B x n doubles in [0,1], the values URAND()
+ * (include/utility.h:36) would return for start b, in draw order (grasp draws exactly n per
+ * call, src/heuristics.c:127); ignored for greedy.  Outputs: successor lists and obj (obj is
+ * the reference's reported value, i.e. GRASP's closing edge counted twice, :135,:152).
+ * status_out[B] (may be NULL) receives 0 or TSP_WRONG_STARTING_NODE per start. */
+int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, const double *urand,
+                      int *succ, int succ_stride, int64_t tour_stride, double *obj, int *status_out);
+
+/* ---- 2-opt on host-resident tours: replaces alg_2opt / alg_2opt_tabu(skip_edge==NULL) ------ */
+/* B tours in/out.  obj[B] in/out: FIRST adds the applied deltas to the incoming value like
+ * `obj_best += delta` (src/heuristics.c:486); BEST overwrites it with the recomputed tour cost
+ * (src/tabusearch.c:168-172).  time_limit_s <= 0 = unlimited.  stats may be NULL, else B entries. */
+int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, int succ_stride,
+                    int64_t tour_stride, double *obj, double time_limit_s, tsp_two_opt_stats *stats);
+
+/* ---- tabu stamps + alg_2opt_tabu with skip_edge != NULL (src/tabusearch.c:107-178) --------- */
+int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out); /* all stamps 0 (CALLOC, :195) */
+void tsp_dev_tabu_destroy(tsp_dev_tabu *tabu);
+/* stamps[idx[k]] = value[k]; idx = x_udir_pos(i,j,n) (src/utility.c:17-30), as :306-309 */
+int tsp_dev_tabu_set(tsp_dev_tabu *tabu, const int *idx, const int *value, int count);
+int tsp_dev_tabu_get(tsp_dev_tabu *tabu, const int *idx, int *value, int count);
+int tsp_dev_tabu_upload(tsp_dev_tabu *tabu, const int *stamps);   /* n(n-1)/2 ints */
+int tsp_dev_tabu_download(tsp_dev_tabu *tabu, int *stamps);
+/* One call of alg_2opt_tabu(inst, skip_edge, stored_prev, iter, tenure) on one tour.
+ * stored_prev (may be NULL) receives the predecessor array (:173-175). */
+int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int tenure, int *succ,
+                         int succ_stride, double *obj, int *stored_prev, double time_limit_s,
+                         tsp_two_opt_stats *stats);
+
+/* ---- tour cost: fitness() for B permutations (src/genetic.c:51-60) ------------------------- */
+int tsp_dev_perm_cost(tsp_dev_inst *inst, int B, const int *perm, int64_t perm_stride, double *cost);
+
+/* ---- device-resident tours (what bench.py times: inputs already in HBM) -------------------- */
+int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out);
+void tsp_dev_tours_destroy(tsp_dev_tours *t);
+/* Upload B successor lists (+ their obj values) and remember them as the reset point. */
+int tsp_dev_tours_upload(tsp_dev_tours *t, const int *succ, int succ_stride, int64_t tour_stride,
+                         const double *obj);
+/* Restore the uploaded tours on the device (device-to-device). */
+int tsp_dev_tours_reset(tsp_dev_tours *t);
+int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t tour_stride,
+                           double *obj, tsp_two_opt_stats *stats);
+/* Run at most max_steps GRID-engine steps (one step = one scan launch + one apply launch per
+ * tour batch) in `mode`; max_steps < 0 = until every tour is at its local optimum.
+ * Does not wait for completion unless `sync` != 0.  *all_done (if not NULL, sync only). */
+int tsp_dev_tours_run(tsp_dev_tours *t, int mode, int64_t max_steps, double time_limit_s, int sync,
+                      int *all_done);
+/* Launch the scan kernel alone `reps` times on the current tours (BEST mode, full sweep) with
+ * HIP events around each launch on the engine's stream; returns the mean launch duration in
+ * *mean_ms and the pairs evaluated per launch in *evals_per_launch.  Roofline measurement. */
+int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t *evals_per_launch);
+/* min over tours of (cost, tour index) packed as (int64(cost) << 24 | index); the value the
+ * multi-start all-reduce(min) combines across ranks.  true_cost != 0 recomputes the cost from
+ * the tour (GRASP's reported value carries an offset).  Written to *packed. */
+int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

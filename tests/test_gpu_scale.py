@@ -1,0 +1,76 @@
+"""GPU, BASELINE.json's full sizes: parity with the oracle where it finishes in seconds and
+size-independent properties elsewhere."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import golden, load_instance
+
+pytestmark = pytest.mark.gpu
+APB = golden("survey_appendix_b.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from tsp_optimization_amd import engine as E
+    assert E.device_count() >= 1
+    return E
+
+
+@pytest.fixture(scope="module")
+def ctx(eng):
+    c = eng.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["rand5000", "rand10000"])
+def test_first_improvement_full_size_matches_reference_counters(eng, ctx, name):
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+    e = APB[name]
+    assert obj[0] == e["greedy"]
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=eng.FIRST)
+    inst.close()
+    assert O.is_tour(s)
+    assert (o, st["sweeps"], st["evals"], st["moves"]) == \
+        (e["first"]["cost"], e["first"]["sw"], e["first"]["ev"], e["first"]["mv"])
+    assert o == O.succ_cost(xy, wt, s)
+
+
+def test_best_improvement_rand2000_matches_reference_counters(eng, ctx):
+    xy, wt = load_instance("rand2000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+    e = APB["rand2000"]
+    assert obj[0] == e["greedy"]
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=eng.BEST)
+    inst.close()
+    assert (o, st["sweeps"], st["evals"], st["moves"]) == \
+        (e["best"]["cost"], e["best"]["sw"], e["best"]["ev"], e["best"]["mv"])
+
+
+def test_best_improvement_rand10000_properties(eng, ctx):
+    """The CPU needs ~0.5 h for this descent; check what does not need it: a valid tour, cost equal
+    to the recomputed cost, strictly fewer sweeps than n, idempotence (a second run makes no move),
+    and the first 3 sweeps equal to the oracle's."""
+    xy, wt = load_instance("rand10000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    _, es, eo, est, tr, _ = O.two_opt_best(xy, wt, succ0, max_sweeps=3, trace_cap=3)
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ0, obj0)
+    tours.run(eng.BEST, max_steps=3)
+    s3, _, st3 = tours.download()
+    tours.close()
+    assert (s3[0] == es).all() and st3[0]["moves"] == 3
+    rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.BEST)
+    assert O.is_tour(s) and o == O.succ_cost(xy, wt, s) and o < obj0
+    assert st["moves"] == st["sweeps"] - 1
+    rc2, s2, o2, st2 = inst.two_opt(s, o, mode=eng.BEST)
+    assert st2["moves"] == 0 and (s2 == s).all() and o2 == o
+    # a best-improvement local optimum is also a first-improvement local optimum
+    rc3, s3b, o3, st3b = inst.two_opt(s, o, mode=eng.FIRST)
+    assert st3b["moves"] == 0 and st3b["sweeps"] == 1 and st3b["evals"] == 10000 * 9999 // 2 - 10000
+    inst.close()

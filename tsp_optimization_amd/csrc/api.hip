@@ -1,0 +1,256 @@
+// api.hip -- context / instance handles and the host-tour entry points of include/tsp_hip.h.
+#include "tsp_internal.hpp"
+
+#include <algorithm>
+#include <time.h>
+
+#pragma clang fp contract(off)
+
+using namespace tsp;
+
+// implemented in two_opt_grid.hip / two_opt_lds.hip
+int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure, int64_t max_steps,
+                 double time_limit_s, int sync, int *all_done);
+int tsp_lds_two_opt(tsp_dev_inst *inst, int mode, int B, int *succ, int succ_stride, int64_t tour_stride,
+                    double *obj, double time_limit_s, tsp_two_opt_stats *stats);
+bool tsp_lds_fits(const tsp_dev_inst *inst);
+
+namespace tsp {
+static thread_local char g_last_error[512] = "";
+void set_last_error(const char *what, hipError_t e, const char *file, int line) {
+    snprintf(g_last_error, sizeof g_last_error, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
+}
+}  // namespace tsp
+
+namespace {
+double wall_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+template <int WT, bool INT>
+__global__ void k_dist_pairs(const double2 *__restrict__ coord, const int *__restrict__ pi,
+                             const int *__restrict__ pj, int count, double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const double2 a = coord[pi[t]], b = coord[pj[t]];
+    out[t] = dist_xy<WT, INT>(a.x, a.y, b.x, b.y);
+}
+
+// genetic.c:51-60 : one wave per permutation would leave the sum order free; the reference adds
+// edge by edge, so one block stages the edge lengths and thread 0 adds them in order when the
+// costs are not integer-valued.
+template <int WT, bool INT>
+__global__ __launch_bounds__(256) void k_perm_cost(const double2 *__restrict__ coord, const int *__restrict__ perm,
+                                                   long long perm_stride, int n, double *__restrict__ cost) {
+    const int *p = perm + (size_t)blockIdx.x * perm_stride;
+    __shared__ double s_part[256];
+    __shared__ double s_chunk[2048];
+    const int tid = threadIdx.x;
+    if constexpr (INT) {
+        double acc = 0.0;
+        for (int k = tid; k < n; k += 256) {
+            const double2 a = coord[p[k]], b = coord[p[k + 1 == n ? 0 : k + 1]];
+            acc += dist_xy<WT, INT>(a.x, a.y, b.x, b.y);
+        }
+        s_part[tid] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) s_part[tid] += s_part[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) cost[blockIdx.x] = s_part[0];
+    } else {
+        double acc = 0.0;
+        for (int base = 0; base < n; base += 2048) {
+            __syncthreads();
+            for (int t = tid; t < 2048 && base + t < n; t += 256) {
+                const int k = base + t;
+                const double2 a = coord[p[k]], b = coord[p[k + 1 == n ? 0 : k + 1]];
+                s_chunk[t] = dist_xy<WT, INT>(a.x, a.y, b.x, b.y);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const int m = min(2048, n - base);
+                for (int t = 0; t < m; ++t) acc += s_chunk[t];
+            }
+        }
+        if (tid == 0) cost[blockIdx.x] = acc;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char *tsp_dev_last_error(void) { return tsp::g_last_error; }
+
+int tsp_dev_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int tsp_dev_open(int device, tsp_dev_ctx **out) {
+    if (!out) return TSP_DEV_E_ARG;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        tsp::set_last_error("hipGetDeviceCount", e == hipSuccess ? hipErrorNoDevice : e, __FILE__, __LINE__);
+        return TSP_DEV_E_NODEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return TSP_DEV_E_NODEVICE;
+    tsp_dev_ctx *c = new tsp_dev_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    TSP_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    c->lds_bytes = (int)prop.sharedMemPerBlock;
+    TSP_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return TSP_OK;
+}
+
+void tsp_dev_close(tsp_dev_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+int tsp_dev_synchronize(tsp_dev_ctx *ctx) {
+    if (!ctx) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+void *tsp_dev_stream(tsp_dev_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_type, int integer_cost,
+                        tsp_dev_inst **out) {
+    if (!ctx || !xy || !out || n < 4) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(ctx->device));
+    tsp_dev_inst *inst = new tsp_dev_inst();
+    inst->ctx = ctx;
+    inst->n = n;
+    // unknown types (the reference's parser leaves -1) use EUC_2D: src/distutil.c:90-91
+    inst->wtype = (weight_type >= 0 && weight_type <= 5) ? weight_type : TSP_EUC_2D;
+    inst->integer_cost = integer_cost ? 1 : 0;
+    inst->h_xy.assign(xy, xy + 2 * (size_t)n);
+    std::vector<double2> c((size_t)n);
+    for (int v = 0; v < n; ++v) {
+        if (inst->wtype == TSP_GEO) { c[v].x = geo_radians(xy[2 * v]); c[v].y = geo_radians(xy[2 * v + 1]); }
+        else { c[v].x = xy[2 * v]; c[v].y = xy[2 * v + 1]; }
+    }
+    TSP_HIP_TRY(hipMalloc(&inst->d_coord, sizeof(double2) * (size_t)n));
+    TSP_HIP_TRY(hipMemcpyAsync(inst->d_coord, c.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = inst;
+    return TSP_OK;
+}
+
+void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
+    if (!inst) return;
+    (void)hipSetDevice(inst->ctx->device);
+    (void)hipStreamSynchronize(inst->ctx->stream);
+    (void)hipFree(inst->d_coord);
+    delete inst;
+}
+
+int tsp_dev_inst_size(const tsp_dev_inst *inst) { return inst ? inst->n : 0; }
+
+int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count, double *out) {
+    if (!inst || !i || !j || !out || count < 0) return TSP_DEV_E_ARG;
+    if (count == 0) return TSP_OK;
+    for (int k = 0; k < count; ++k)
+        if (i[k] < 0 || i[k] >= inst->n || j[k] < 0 || j[k] >= inst->n) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    hipStream_t s = inst->ctx->stream;
+    int *d_i = nullptr, *d_j = nullptr;
+    double *d_o = nullptr;
+    TSP_HIP_TRY(hipMalloc(&d_i, sizeof(int) * (size_t)count));
+    TSP_HIP_TRY(hipMalloc(&d_j, sizeof(int) * (size_t)count));
+    TSP_HIP_TRY(hipMalloc(&d_o, sizeof(double) * (size_t)count));
+    TSP_HIP_TRY(hipMemcpyAsync(d_i, i, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
+    TSP_HIP_TRY(hipMemcpyAsync(d_j, j, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
+    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+        hipLaunchKernelGGL((k_dist_pairs<WTC, INTC>), dim3((count + 255) / 256), dim3(256), 0, s, inst->d_coord, d_i,
+                           d_j, count, d_o);
+    });
+    TSP_HIP_TRY(hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o);
+    return TSP_OK;
+}
+
+int tsp_dev_perm_cost(tsp_dev_inst *inst, int B, const int *perm, int64_t perm_stride, double *cost) {
+    if (!inst || !perm || !cost || B < 1 || perm_stride < inst->n) return TSP_DEV_E_ARG;
+    const int n = inst->n;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < n; ++k) {
+            const int v = perm[(size_t)b * perm_stride + k];
+            if (v < 0 || v >= n) return TSP_DEV_E_ARG;
+        }
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    hipStream_t s = inst->ctx->stream;
+    int *d_p = nullptr;
+    double *d_c = nullptr;
+    const size_t words = (size_t)(B - 1) * perm_stride + n;
+    TSP_HIP_TRY(hipMalloc(&d_p, sizeof(int) * words));
+    TSP_HIP_TRY(hipMalloc(&d_c, sizeof(double) * (size_t)B));
+    TSP_HIP_TRY(hipMemcpyAsync(d_p, perm, sizeof(int) * words, hipMemcpyHostToDevice, s));
+    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+        hipLaunchKernelGGL((k_perm_cost<WTC, INTC>), dim3(B), dim3(256), 0, s, inst->d_coord, d_p,
+                           (long long)perm_stride, n, d_c);
+    });
+    TSP_HIP_TRY(hipMemcpyAsync(cost, d_c, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    (void)hipFree(d_p); (void)hipFree(d_c);
+    return TSP_OK;
+}
+
+int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, int succ_stride,
+                    int64_t tour_stride, double *obj, double time_limit_s, tsp_two_opt_stats *stats) {
+    if (!inst || !succ || !obj || B < 1 || succ_stride < 1) return TSP_DEV_E_ARG;
+    if (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST) return TSP_DEV_E_ARG;
+    if (engine == TSP_ENGINE_AUTO) engine = TSP_ENGINE_GRID;
+    if (engine == TSP_ENGINE_LDS) {
+        if (!tsp_lds_fits(inst)) return TSP_DEV_E_ARG;
+        return tsp_lds_two_opt(inst, mode, B, succ, succ_stride, tour_stride, obj, time_limit_s, stats);
+    }
+    const double t0 = wall_s();
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    hipStream_t s = inst->ctx->stream;
+    tsp_dev_tours *t = nullptr;
+    int rc = tsp_dev_tours_create(inst, B, &t);
+    if (rc) return rc;
+    rc = tsp_dev_tours_upload(t, succ, succ_stride, tour_stride, obj);
+    if (rc) { tsp_dev_tours_destroy(t); return rc; }
+    hipEvent_t e0, e1;
+    TSP_HIP_TRY(hipEventCreate(&e0));
+    TSP_HIP_TRY(hipEventCreate(&e1));
+    TSP_HIP_TRY(hipEventRecord(e0, s));
+    int done = 0;
+    int status = tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
+    TSP_HIP_TRY(hipEventRecord(e1, s));
+    TSP_HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TSP_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (status < 0) { tsp_dev_tours_destroy(t); return status; }
+    std::vector<double> new_obj((size_t)B);
+    rc = tsp_dev_tours_download(t, succ, succ_stride, tour_stride, new_obj.data(), stats);
+    if (rc == TSP_OK) {
+        for (int b = 0; b < B; ++b) {
+            // BEST stopped by the time limit has no recomputed cost yet: do what tabusearch.c:168-172 does
+            obj[b] = new_obj[b];
+        }
+        if (stats) for (int b = 0; b < B; ++b) { stats[b].seconds = wall_s() - t0; stats[b].device_ms = ms; }
+    }
+    tsp_dev_tours_destroy(t);
+    return rc ? rc : status;
+}
+
+}  // extern "C"

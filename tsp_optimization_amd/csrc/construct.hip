@@ -1,0 +1,250 @@
+// construct.hip -- greedy() / grasp() (src/heuristics.c:18-156) for B starting nodes at once, and the
+// n x n distance matrix build.
+//
+// Construction: one workgroup per start.  Each of the n steps is a block-wide arg-min of
+// calc_dist(cur, k) over the unvisited k, lowest index winning ties (the reference's strict '<'
+// scan in index order, :51 / :117).  GRASP's runner-up is "the running minimum just before the
+// final one" (:117-122), i.e. the arg-min over unvisited k < best -- a second, shorter arg-min that
+// is only needed on the ~10 % of steps whose draw is >= GRASP_RAND (:127-128).
+#include "tsp_internal.hpp"
+
+#include <cfloat>
+
+#pragma clang fp contract(off)
+
+namespace tsp {
+
+constexpr int kConsThreads = 1024;
+constexpr double kGraspPickBest = 0.9;  // src/heuristics.c:10
+
+struct ArgMin {
+    double d;
+    int k;
+};
+
+__device__ __forceinline__ bool lt(const ArgMin &a, const ArgMin &b) { return a.d < b.d || (a.d == b.d && a.k < b.k); }
+
+// block-wide (d, k) lexicographic minimum; k == INT_MAX means "none"
+__device__ __forceinline__ ArgMin block_argmin(ArgMin v, double *s_d, int *s_k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ArgMin o;
+        o.d = __shfl_xor(v.d, off);
+        o.k = __shfl_xor(v.k, off);
+        if (lt(o, v)) v = o;
+    }
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if ((tid & 63) == 0) { s_d[tid >> 6] = v.d; s_k[tid >> 6] = v.k; }
+    __syncthreads();
+    ArgMin r;
+    r.d = s_d[0]; r.k = s_k[0];
+    for (int w = 1; w < kConsThreads / 64; ++w) {
+        ArgMin o;
+        o.d = s_d[w]; o.k = s_k[w];
+        if (lt(o, r)) r = o;
+    }
+    return r;
+}
+
+template <int WT, bool INT, bool IS_GRASP>
+__global__ __launch_bounds__(kConsThreads) void k_construct(const double2 *__restrict__ coord, int n,
+                                                           const int *__restrict__ starts,
+                                                           const double *__restrict__ urand,
+                                                           unsigned char *__restrict__ visited_all,
+                                                           int *__restrict__ succ_all, double *__restrict__ obj,
+                                                           int *__restrict__ status) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int start = starts[b];
+    if (start < 0 || start >= n) {  // heuristics.c:20 / :84 (negative starts would index out of bounds there)
+        if (tid == 0) { status[b] = TSP_WRONG_STARTING_NODE; obj[b] = 0.0; }
+        return;
+    }
+    unsigned char *visited = visited_all + (size_t)b * n;
+    int *succ = succ_all + (size_t)b * n;
+    const double *u = IS_GRASP ? urand + (size_t)b * n : nullptr;
+    __shared__ double s_d[kConsThreads / 64];
+    __shared__ int s_k[kConsThreads / 64];
+
+    for (int k = tid; k < n; k += kConsThreads) visited[k] = (k == start) ? 1 : 0;
+    __syncthreads();
+
+    double total = 0.0;
+    int cur = start;
+    for (int step = 0;; ++step) {
+        const double2 c = coord[cur];
+        ArgMin mine;
+        mine.d = DBL_MAX; mine.k = 0x7fffffff;
+        for (int k = tid; k < n; k += kConsThreads) {
+            if (k == cur || visited[k]) continue;
+            const double2 o = coord[k];
+            const double d = dist_xy<WT, INT>(c.x, c.y, o.x, o.y);
+            if (d < mine.d) { mine.d = d; mine.k = k; }
+        }
+        const ArgMin best = block_argmin(mine, s_d, s_k);
+        int pick = best.k == 0x7fffffff ? -1 : best.k;
+        double pick_d = best.d;
+        if constexpr (IS_GRASP) {
+            const double draw = u[step];
+            if (!(draw < kGraspPickBest) && pick >= 0) {
+                ArgMin m2;
+                m2.d = DBL_MAX; m2.k = 0x7fffffff;
+                for (int k = tid; k < pick; k += kConsThreads) {
+                    if (k == cur || visited[k]) continue;
+                    const double2 o = coord[k];
+                    const double d = dist_xy<WT, INT>(c.x, c.y, o.x, o.y);
+                    if (d < m2.d) { m2.d = d; m2.k = k; }
+                }
+                const ArgMin runner = block_argmin(m2, s_d, s_k);
+                if (runner.k != 0x7fffffff) { pick = runner.k; pick_d = runner.d; }
+            }
+        }
+        if (pick < 0) {  // every node visited: close the cycle
+            if (tid == 0) succ[cur] = start;
+            if constexpr (IS_GRASP) {  // heuristics.c:135
+                const double2 s0 = coord[start];
+                total += dist_xy<WT, INT>(c.x, c.y, s0.x, s0.y);
+            }
+            break;
+        }
+        if (tid == 0) { succ[cur] = pick; visited[pick] = 1; }
+        total += pick_d;
+        cur = pick;
+        __syncthreads();  // visited[pick] before the next scan
+    }
+    {   // heuristics.c:74 / :152
+        const double2 c = coord[cur], s0 = coord[start];
+        total += dist_xy<WT, INT>(c.x, c.y, s0.x, s0.y);
+    }
+    if (tid == 0) { obj[b] = total; status[b] = TSP_OK; }
+}
+
+// ---- distance matrix ------------------------------------------------------------------------
+// Block = one row i x 1024 columns; each lane computes 4 consecutive entries and stores 16 B
+// (int32) or 32 B (double).  The row's coordinates are wave-uniform.  Write-bandwidth bound:
+// 4 n^2 (int32) or 8 n^2 (double) bytes to HBM against 16 n bytes of coordinates.
+template <int WT, bool INT, typename OUT>
+__global__ __launch_bounds__(256) void k_dist_matrix(const double2 *__restrict__ coord, int n, OUT *__restrict__ out) {
+    const int i = blockIdx.y;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= n) return;
+    const double2 ci = coord[i];
+    OUT v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = min(j0 + k, n - 1);
+        const double2 cj = coord[j];
+        const double d = (j == i) ? 0.0 : dist_xy<WT, INT>(ci.x, ci.y, cj.x, cj.y);
+        v[k] = (OUT)d;
+    }
+    OUT *row = out + (size_t)i * n;
+    if (j0 + 3 < n && (((size_t)i * n + j0) * sizeof(OUT)) % 16 == 0) {
+        if constexpr (sizeof(OUT) == 4) {
+            *reinterpret_cast<int4 *>(row + j0) = make_int4((int)v[0], (int)v[1], (int)v[2], (int)v[3]);
+        } else {
+            *reinterpret_cast<double2 *>(row + j0) = make_double2((double)v[0], (double)v[1]);
+            *reinterpret_cast<double2 *>(row + j0 + 2) = make_double2((double)v[2], (double)v[3]);
+        }
+    } else {
+        for (int k = 0; k < 4 && j0 + k < n; ++k) row[j0 + k] = v[k];
+    }
+}
+
+}  // namespace tsp
+
+using namespace tsp;
+
+extern "C" {
+
+int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, const double *urand, int *succ,
+                      int succ_stride, int64_t tour_stride, double *obj, int *status_out) {
+    if (!inst || !starts || !succ || !obj || B < 1 || succ_stride < 1) return TSP_DEV_E_ARG;
+    if (kind != TSP_CONSTRUCT_GREEDY && kind != TSP_CONSTRUCT_GRASP) return TSP_DEV_E_ARG;
+    if (kind == TSP_CONSTRUCT_GRASP && !urand) return TSP_DEV_E_ARG;
+    const int n = inst->n;
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    hipStream_t s = inst->ctx->stream;
+    int *d_starts = nullptr, *d_succ = nullptr, *d_status = nullptr;
+    double *d_urand = nullptr, *d_obj = nullptr;
+    unsigned char *d_vis = nullptr;
+    TSP_HIP_TRY(hipMalloc(&d_starts, sizeof(int) * (size_t)B));
+    TSP_HIP_TRY(hipMalloc(&d_status, sizeof(int) * (size_t)B));
+    TSP_HIP_TRY(hipMalloc(&d_obj, sizeof(double) * (size_t)B));
+    TSP_HIP_TRY(hipMalloc(&d_succ, sizeof(int) * (size_t)B * n));
+    TSP_HIP_TRY(hipMalloc(&d_vis, (size_t)B * n));
+    TSP_HIP_TRY(hipMemcpyAsync(d_starts, starts, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+    TSP_HIP_TRY(hipMemsetAsync(d_succ, 0, sizeof(int) * (size_t)B * n, s));  // CALLOC'd edges, solver.c:270
+    if (kind == TSP_CONSTRUCT_GRASP) {
+        TSP_HIP_TRY(hipMalloc(&d_urand, sizeof(double) * (size_t)B * n));
+        TSP_HIP_TRY(hipMemcpyAsync(d_urand, urand, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, s));
+    }
+    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+        if (kind == TSP_CONSTRUCT_GRASP)
+            hipLaunchKernelGGL((k_construct<WTC, INTC, true>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
+                               d_starts, d_urand, d_vis, d_succ, d_obj, d_status);
+        else
+            hipLaunchKernelGGL((k_construct<WTC, INTC, false>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
+                               d_starts, (const double *)nullptr, d_vis, d_succ, d_obj, d_status);
+    });
+    std::vector<int> h_succ((size_t)B * n), h_status((size_t)B);
+    TSP_HIP_TRY(hipMemcpyAsync(h_succ.data(), d_succ, sizeof(int) * (size_t)B * n, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipMemcpyAsync(h_status.data(), d_status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipMemcpyAsync(obj, d_obj, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    int worst = TSP_OK;
+    for (int b = 0; b < B; ++b) {
+        if (status_out) status_out[b] = h_status[b];
+        if (h_status[b] != TSP_OK) { worst = h_status[b]; continue; }  // edges untouched, like :20
+        int *sp = succ + (size_t)b * tour_stride;
+        for (int v = 0; v < n; ++v) sp[(size_t)v * succ_stride] = h_succ[(size_t)b * n + v];
+    }
+    (void)hipFree(d_starts); (void)hipFree(d_status); (void)hipFree(d_obj); (void)hipFree(d_succ);
+    (void)hipFree(d_vis); (void)hipFree(d_urand);
+    return (B == 1) ? worst : TSP_OK;
+}
+
+int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float *kernel_ms) {
+    if (!inst) return TSP_DEV_E_ARG;
+    if (as_int32 && !inst->integer_cost && inst->wtype != TSP_CEIL_2D) return TSP_DEV_E_ARG;
+    const int n = inst->n;
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    hipStream_t s = inst->ctx->stream;
+    const size_t bytes = (size_t)n * n * (as_int32 ? 4 : 8);
+    void *d_out = nullptr;
+    TSP_HIP_TRY(hipMalloc(&d_out, bytes));
+    hipEvent_t e0, e1;
+    TSP_HIP_TRY(hipEventCreate(&e0));
+    TSP_HIP_TRY(hipEventCreate(&e1));
+    const dim3 grid((n + 1023) / 1024, n);
+    const int reps = out_host ? 1 : 5;  // timing-only calls: warm once, then average
+    float ms = 0.f;
+    for (int r = 0; r < reps + (out_host ? 0 : 1); ++r) {
+        TSP_HIP_TRY(hipEventRecord(e0, s));
+        TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+            if (as_int32)
+                hipLaunchKernelGGL((k_dist_matrix<WTC, INTC, int>), grid, dim3(256), 0, s, inst->d_coord, n, (int *)d_out);
+            else
+                hipLaunchKernelGGL((k_dist_matrix<WTC, INTC, double>), grid, dim3(256), 0, s, inst->d_coord, n,
+                                   (double *)d_out);
+        });
+        TSP_HIP_TRY(hipEventRecord(e1, s));
+        TSP_HIP_TRY(hipEventSynchronize(e1));
+        float one = 0.f;
+        TSP_HIP_TRY(hipEventElapsedTime(&one, e0, e1));
+        if (out_host || r > 0) ms += one;
+    }
+    ms /= (float)reps;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (out_host) {
+        TSP_HIP_TRY(hipMemcpyAsync(out_host, d_out, bytes, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+    }
+    TSP_HIP_TRY(hipGetLastError());
+    (void)hipFree(d_out);
+    if (kernel_ms) *kernel_ms = ms;
+    return TSP_OK;
+}
+
+}  // extern "C"

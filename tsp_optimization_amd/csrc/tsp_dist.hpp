@@ -1,0 +1,93 @@
+// tsp_dist.hpp -- device-side distance functions (gfx950), bit-compatible with the reference's
+// calc_dist (src/distutil.c:73-92) for every metric whose arithmetic is IEEE basic operations
+// + sqrt (EUC_2D, ATT, CEIL_2D, MAN_2D, MAX_2D).  GEO needs cos/acos, where ocml and glibc
+// differ in the last ulp: tolerance tier.
+//
+// Rules that make the results equal to x86-64 gcc's (which never fuses a*b+c without -mfma):
+//   - this translation unit is compiled with -ffp-contract=off and the pragma below repeats it;
+//   - sqrt() on double is the correctly rounded ocml/LLVM expansion (no -ffast-math);
+//   - nint(x) = (double)(long)(x + 0.5) == trunc(x + 0.5) for the non-negative values that occur.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
+namespace tsp {
+
+enum : int { WT_EUC_2D = 0, WT_MAX_2D = 1, WT_MAN_2D = 2, WT_CEIL_2D = 3, WT_GEO = 4, WT_ATT = 5 };
+
+// include/distutil.h:6-7
+#define TSP_GEO_PI 3.14159265358979323846264
+#define TSP_GEO_RADIUS 6378.388
+
+// src/distutil.c:4-6
+__device__ __forceinline__ double nint_pos(double v) { return trunc(v + 0.5); }
+
+// src/distutil.c:51-58 : degrees.minutes -> radians; (long) truncates toward zero like trunc()
+__device__ __host__ __forceinline__ double geo_radians(double v) {
+    double deg = (double)(long long)v;
+    double frac = v - deg;
+    return TSP_GEO_PI * (deg + 5.0 * frac / 3.0) / 180.0;
+}
+
+// Distance between two nodes given their coordinate pairs.  For WT_GEO the pairs are
+// (latitude, longitude) in radians as produced by geo_radians() at upload time; for every other
+// type they are the raw (x, y).  Unknown weight types fall back to EUC_2D (src/distutil.c:90-91),
+// which the host maps before choosing the template instance.
+template <int WT, bool INT>
+__device__ __forceinline__ double dist_xy(double ax, double ay, double bx, double by) {
+    if constexpr (WT == WT_ATT) {                       // src/distutil.c:20-31
+        const double dx = ax - bx, dy = ay - by;
+        const double r = sqrt((dx * dx + dy * dy) / 10.0);
+        if constexpr (!INT) return r;
+        const double t = nint_pos(r);
+        return t < r ? t + 1.0 : t;
+    } else if constexpr (WT == WT_MAN_2D) {             // src/distutil.c:33-37, dy = |by - by|
+        const double dx = fabs(ax - bx), dy = fabs(by - by);
+        return INT ? nint_pos(dx + dy) : dx + dy;
+    } else if constexpr (WT == WT_MAX_2D) {             // src/distutil.c:39-45, dy = |by - by|
+        double dx = fabs(ax - bx), dy = fabs(by - by);
+        if constexpr (INT) { dx = nint_pos(dx); dy = nint_pos(dy); }
+        return dx > dy ? dx : dy;
+    } else if constexpr (WT == WT_CEIL_2D) {            // src/distutil.c:47-49
+        const double dx = ax - bx, dy = ay - by;
+        return ceil(sqrt(dx * dx + dy * dy));
+    } else if constexpr (WT == WT_GEO) {                // src/distutil.c:60-71
+        const double q1 = cos(ay - by);
+        const double q2 = cos(ax - bx);
+        const double q3 = cos(ax + bx);
+        const double d = TSP_GEO_RADIUS * acos(0.5 * ((1.0 + q1) * q2 - (1.0 - q1) * q3)) + 1.0;
+        return INT ? nint_pos(d) : d;
+    } else {                                            // src/distutil.c:13-18
+        const double dx = ax - bx, dy = ay - by;
+        const double d = sqrt(dx * dx + dy * dy);
+        return INT ? nint_pos(d) : d;
+    }
+}
+
+// Runtime dispatch over (weight type, integer cost) -> template instance.
+#define TSP_DISPATCH_METRIC(WT_RT, INT_RT, ...)                                               \
+    do {                                                                                      \
+        const int wt__ = (WT_RT);                                                             \
+        const bool int__ = (INT_RT) != 0;                                                     \
+        auto call__ = [&](auto wt_c, auto int_c) {                                            \
+            constexpr int WTC = decltype(wt_c)::value;                                        \
+            constexpr bool INTC = decltype(int_c)::value;                                     \
+            __VA_ARGS__                                                                       \
+        };                                                                                    \
+        auto pick_int__ = [&](auto wt_c) {                                                    \
+            if (int__) call__(wt_c, std::true_type{}); else call__(wt_c, std::false_type{});  \
+        };                                                                                    \
+        switch (wt__) {                                                                       \
+        case tsp::WT_ATT: pick_int__(std::integral_constant<int, tsp::WT_ATT>{}); break;       \
+        case tsp::WT_MAN_2D: pick_int__(std::integral_constant<int, tsp::WT_MAN_2D>{}); break; \
+        case tsp::WT_MAX_2D: pick_int__(std::integral_constant<int, tsp::WT_MAX_2D>{}); break; \
+        case tsp::WT_CEIL_2D: pick_int__(std::integral_constant<int, tsp::WT_CEIL_2D>{}); break; \
+        case tsp::WT_GEO: pick_int__(std::integral_constant<int, tsp::WT_GEO>{}); break;       \
+        default: pick_int__(std::integral_constant<int, tsp::WT_EUC_2D>{}); break;             \
+        }                                                                                     \
+    } while (0)
+
+}  // namespace tsp

@@ -1,0 +1,118 @@
+// tsp_internal.hpp -- data laid out in HBM and the opaque handle types behind include/tsp_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/tsp_hip.h"
+#include "tsp_dist.hpp"
+
+namespace tsp {
+
+// Per-node record, one array of n per tour, indexed by NODE id (the reference scans pairs in
+// node-id order, src/heuristics.c:452-454).  48 bytes = three 16-byte loads per lane; a row's
+// record is wave-uniform and comes through the scalar cache.
+//   x, y    : this node's coordinates (static; lat/lon radians for GEO)
+//   xs, ys  : coordinates of succ(node)                    } rewritten by the apply kernel for
+//   ds      : calc_dist(node, succ(node))                  } the nodes a move touches
+//   succ    : succ(node), for the adjacency skip rules (heuristics.c:471, tabusearch.c:134)
+struct alignas(16) Rec {
+    double x, y;
+    double xs, ys;
+    double ds;
+    int succ;
+    int pad;
+};
+static_assert(sizeof(Rec) == 48, "Rec must be 48 bytes");
+
+// One scan block's candidate.  i < 0 means "none".
+struct alignas(16) Partial {
+    double delta;
+    int i, j;
+};
+static_assert(sizeof(Partial) == 16, "Partial must be 16 bytes");
+
+// Per-tour control block, read by every scan block (scalar loads) and written by the apply
+// kernel's thread 0.  The descent is driven entirely by this block: the host only polls `done`.
+struct alignas(16) TourState {
+    // FIRST mode cursor: every pair up to and including (ci, cj) in (i<j) lexicographic order has
+    // been scanned in the current sweep; (0,0) at the start of a sweep.
+    int ci, cj;
+    int chunk_rows;   // FIRST: number of rows the next scan covers
+    int done;         // local optimum reached (or nothing to do)
+    double obj;       // FIRST: running obj_best (+= delta); BEST: recomputed cost once done
+    double seen_cost; // FIRST: best_cost of heuristics.c:442,492,495
+    long long sweeps, evals, moves, reversed, pairs_scanned, steps;
+};
+
+constexpr int kScanThreads = 256;
+constexpr int kApplyThreads = 1024;
+
+}  // namespace tsp
+
+// ---- opaque handles ------------------------------------------------------------------------
+
+struct tsp_dev_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int lds_bytes = 0;
+};
+
+struct tsp_dev_inst {
+    tsp_dev_ctx *ctx = nullptr;
+    int n = 0;
+    int wtype = 0;        // mapped: unknown -> EUC_2D
+    int integer_cost = 1;
+    double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO
+    std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
+};
+
+struct tsp_dev_tabu {
+    tsp_dev_inst *inst = nullptr;
+    long long count = 0;
+    int *d_stamp = nullptr;
+};
+
+struct tsp_dev_tours {
+    tsp_dev_inst *inst = nullptr;
+    int B = 0;
+    int n = 0;
+    // device
+    int *d_order = nullptr;          // B x n : node at tour position p
+    int *d_pos = nullptr;            // B x n : position of node v
+    tsp::Rec *d_rec = nullptr;       // B x n
+    tsp::TourState *d_state = nullptr;
+    tsp::Partial *d_partial = nullptr;
+    size_t partial_per_tour = 0;
+    int *d_slot_evals = nullptr;     // per scan block: pairs evaluated (tabu runs only)
+    // reset point (device copies of the uploaded tours)
+    int *d_order0 = nullptr;
+    std::vector<double> h_obj0;
+    // pinned host mirror of the states, for polling
+    tsp::TourState *h_state = nullptr;
+    // scan geometry
+    int first_rows_per_block = 4;
+    int first_max_rows = 2048;
+    int best_rows_per_block = 32;
+    // accumulated device time
+    double device_ms = 0.0;
+};
+
+// ---- error plumbing ------------------------------------------------------------------------
+namespace tsp {
+void set_last_error(const char *what, hipError_t e, const char *file, int line);
+}
+#define TSP_HIP_TRY(expr)                                                    \
+    do {                                                                     \
+        hipError_t e__ = (expr);                                             \
+        if (e__ != hipSuccess) {                                             \
+            tsp::set_last_error(#expr, e__, __FILE__, __LINE__);             \
+            return TSP_DEV_E_HIP;                                            \
+        }                                                                    \
+    } while (0)

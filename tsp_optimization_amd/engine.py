@@ -1,0 +1,312 @@
+"""ctypes binding of include/tsp_hip.h (libtsp_hip.so).  No fallback of any kind: if the library
+is missing or no MI355X is visible the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+EUC_2D, MAX_2D, MAN_2D, CEIL_2D, GEO, ATT = 0, 1, 2, 3, 4, 5
+FIRST, BEST = 0, 1
+GREEDY, GRASP = 0, 1
+ENGINE_AUTO, ENGINE_GRID, ENGINE_LDS = 0, 1, 2
+OK, WRONG_STARTING_NODE, TIME_LIMIT_EXCEEDED = 0, 1, 2
+
+
+class TspDeviceError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [("sweeps", C.c_int64), ("evals", C.c_int64), ("moves", C.c_int64),
+                ("reversed", C.c_int64), ("pairs_scanned", C.c_int64), ("steps", C.c_int64),
+                ("seconds", C.c_double), ("device_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads libtsp_hip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise TspDeviceError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path)
+        L = C.CDLL(path)
+        vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+        sp = C.POINTER(Stats)
+        L.tsp_dev_last_error.restype = C.c_char_p
+        L.tsp_dev_open.argtypes = [C.c_int, C.POINTER(vp)]
+        L.tsp_dev_close.argtypes = [vp]
+        L.tsp_dev_close.restype = None
+        L.tsp_dev_synchronize.argtypes = [vp]
+        L.tsp_dev_stream.argtypes = [vp]
+        L.tsp_dev_stream.restype = vp
+        L.tsp_dev_inst_create.argtypes = [vp, dp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.tsp_dev_inst_destroy.argtypes = [vp]
+        L.tsp_dev_inst_destroy.restype = None
+        L.tsp_dev_inst_size.argtypes = [vp]
+        L.tsp_dev_dist_pairs.argtypes = [vp, ip, ip, C.c_int, dp]
+        L.tsp_dev_dist_matrix.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float)]
+        L.tsp_dev_construct.argtypes = [vp, C.c_int, C.c_int, ip, dp, ip, C.c_int, C.c_int64, dp, ip]
+        L.tsp_dev_two_opt.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int64, dp,
+                                      C.c_double, sp]
+        L.tsp_dev_tabu_create.argtypes = [vp, C.POINTER(vp)]
+        L.tsp_dev_tabu_destroy.argtypes = [vp]
+        L.tsp_dev_tabu_destroy.restype = None
+        L.tsp_dev_tabu_set.argtypes = [vp, ip, ip, C.c_int]
+        L.tsp_dev_tabu_get.argtypes = [vp, ip, ip, C.c_int]
+        L.tsp_dev_tabu_upload.argtypes = [vp, ip]
+        L.tsp_dev_tabu_download.argtypes = [vp, ip]
+        L.tsp_dev_two_opt_tabu.argtypes = [vp, vp, C.c_int, C.c_int, ip, C.c_int, dp, ip, C.c_double, sp]
+        L.tsp_dev_perm_cost.argtypes = [vp, C.c_int, ip, C.c_int64, dp]
+        L.tsp_dev_tours_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.tsp_dev_tours_destroy.argtypes = [vp]
+        L.tsp_dev_tours_destroy.restype = None
+        L.tsp_dev_tours_upload.argtypes = [vp, ip, C.c_int, C.c_int64, dp]
+        L.tsp_dev_tours_reset.argtypes = [vp]
+        L.tsp_dev_tours_download.argtypes = [vp, ip, C.c_int, C.c_int64, dp, sp]
+        L.tsp_dev_tours_run.argtypes = [vp, C.c_int, C.c_int64, C.c_double, C.c_int, ip]
+        L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+        _lib = L
+    return _lib
+
+
+EXPORTED = [
+    "tsp_dev_open", "tsp_dev_close", "tsp_dev_last_error", "tsp_dev_count", "tsp_dev_synchronize",
+    "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size",
+    "tsp_dev_dist_pairs", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_two_opt",
+    "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
+    "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
+    "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
+    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
+]
+
+
+def _check(rc, allow=(OK,)):
+    if rc in allow:
+        return rc
+    msg = lib().tsp_dev_last_error().decode()
+    raise TspDeviceError("tsp_dev call failed with %d %s" % (rc, msg))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def device_count():
+    return lib().tsp_dev_count()
+
+
+class Context:
+    """One device + the engine's stream (tsp_dev_open)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().tsp_dev_open(device, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        _check(lib().tsp_dev_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib().tsp_dev_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Instance:
+    """Node coordinates resident in HBM (tsp_dev_inst_create)."""
+
+    def __init__(self, ctx, xy, wtype, integer_cost=1):
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        assert xy.ndim == 2 and xy.shape[1] == 2
+        self.ctx, self.n, self.wtype, self.integer_cost = ctx, len(xy), wtype, integer_cost
+        self._h = C.c_void_p()
+        _check(lib().tsp_dev_inst_create(ctx._h, _d(xy), self.n, wtype, integer_cost, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tsp_dev_inst_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- calc_dist ------------------------------------------------------------------------
+    def dist_pairs(self, i, j):
+        i = np.ascontiguousarray(i, dtype=np.int32)
+        j = np.ascontiguousarray(j, dtype=np.int32)
+        out = np.empty(len(i), dtype=np.float64)
+        _check(lib().tsp_dev_dist_pairs(self._h, _i(i), _i(j), len(i), _d(out)))
+        return out
+
+    def dist_matrix(self, as_int32=False, fetch=True):
+        """-> (matrix or None, kernel_ms)"""
+        n = self.n
+        out = np.empty((n, n), dtype=np.int32 if as_int32 else np.float64) if fetch else None
+        ms = C.c_float(0)
+        _check(lib().tsp_dev_dist_matrix(self._h, out.ctypes.data_as(C.c_void_p) if fetch else None,
+                                         1 if as_int32 else 0, C.byref(ms)))
+        return out, ms.value
+
+    # -- greedy / grasp -------------------------------------------------------------------
+    def construct(self, kind, starts, urand=None):
+        """-> (succ [B,n] int32, obj [B], status [B])"""
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        B, n = len(starts), self.n
+        succ = np.zeros((B, n), dtype=np.int32)
+        obj = np.zeros(B, dtype=np.float64)
+        status = np.zeros(B, dtype=np.int32)
+        up = None
+        if kind == GRASP:
+            urand = np.ascontiguousarray(urand, dtype=np.float64)
+            assert urand.shape == (B, n)
+            up = _d(urand)
+        _check(lib().tsp_dev_construct(self._h, kind, B, _i(starts), up, _i(succ), 1, n, _d(obj), _i(status)),
+               allow=(OK, WRONG_STARTING_NODE))
+        return succ, obj, status
+
+    # -- alg_2opt / alg_2opt_tabu(NULL) ---------------------------------------------------
+    def two_opt(self, succ, obj, mode=FIRST, engine=ENGINE_AUTO, time_limit=-1.0):
+        """succ [n] or [B,n]; obj scalar or [B].  -> (status, succ', obj', [stats dict])"""
+        succ = np.array(succ, dtype=np.int32, copy=True, order="C")
+        single = succ.ndim == 1
+        succ2 = succ.reshape(1, -1) if single else succ
+        B, n = succ2.shape
+        assert n == self.n
+        o = np.array(np.broadcast_to(np.asarray(obj, dtype=np.float64), (B,)), copy=True)
+        st = (Stats * B)()
+        rc = lib().tsp_dev_two_opt(self._h, mode, engine, B, _i(succ2), 1, n, _d(o), time_limit, st)
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        stats = [s.as_dict() for s in st]
+        if single:
+            return rc, succ2[0], float(o[0]), stats[0]
+        return rc, succ2, o, stats
+
+    def perm_cost(self, perms):
+        perms = np.ascontiguousarray(perms, dtype=np.int32)
+        if perms.ndim == 1:
+            perms = perms.reshape(1, -1)
+        B, n = perms.shape
+        cost = np.zeros(B, dtype=np.float64)
+        _check(lib().tsp_dev_perm_cost(self._h, B, _i(perms), n, _d(cost)))
+        return cost
+
+
+class Tabu:
+    """n(n-1)/2 tabu stamps resident in HBM (tabusearch.c:195)."""
+
+    def __init__(self, inst):
+        self.inst = inst
+        self._h = C.c_void_p()
+        _check(lib().tsp_dev_tabu_create(inst._h, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tsp_dev_tabu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set(self, idx, value):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        value = np.ascontiguousarray(value, dtype=np.int32)
+        _check(lib().tsp_dev_tabu_set(self._h, _i(idx), _i(value), len(idx)))
+
+    def get(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.zeros(len(idx), dtype=np.int32)
+        _check(lib().tsp_dev_tabu_get(self._h, _i(idx), _i(out), len(idx)))
+        return out
+
+    def upload(self, stamps):
+        stamps = np.ascontiguousarray(stamps, dtype=np.int32)
+        n = self.inst.n
+        assert len(stamps) == n * (n - 1) // 2
+        _check(lib().tsp_dev_tabu_upload(self._h, _i(stamps)))
+
+    def download(self):
+        n = self.inst.n
+        out = np.zeros(n * (n - 1) // 2, dtype=np.int32)
+        _check(lib().tsp_dev_tabu_download(self._h, _i(out)))
+        return out
+
+    def two_opt(self, succ, iter_, tenure, want_prev=False, time_limit=-1.0):
+        """alg_2opt_tabu(inst, skip_edge, stored_prev, iter, tenure) -> (status, succ', obj', stats, prev)"""
+        succ = np.array(succ, dtype=np.int32, copy=True, order="C")
+        o = C.c_double(0.0)
+        st = Stats()
+        prev = np.zeros(self.inst.n, dtype=np.int32) if want_prev else None
+        rc = lib().tsp_dev_two_opt_tabu(self.inst._h, self._h, iter_, tenure, _i(succ), 1, C.byref(o),
+                                        _i(prev) if want_prev else None, time_limit, C.byref(st))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, succ, o.value, st.as_dict(), prev
+
+
+class Tours:
+    """B tours resident in HBM (what bench.py times)."""
+
+    def __init__(self, inst, B=1):
+        self.inst, self.B = inst, B
+        self._h = C.c_void_p()
+        _check(lib().tsp_dev_tours_create(inst._h, B, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().tsp_dev_tours_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def upload(self, succ, obj):
+        succ = np.ascontiguousarray(succ, dtype=np.int32).reshape(self.B, self.inst.n)
+        o = np.array(np.broadcast_to(np.asarray(obj, dtype=np.float64), (self.B,)), copy=True)
+        _check(lib().tsp_dev_tours_upload(self._h, _i(succ), 1, self.inst.n, _d(o)))
+
+    def reset(self):
+        _check(lib().tsp_dev_tours_reset(self._h))
+
+    def run(self, mode, max_steps=-1, time_limit=-1.0, sync=True):
+        """-> (status, all_done)"""
+        done = C.c_int(0)
+        rc = lib().tsp_dev_tours_run(self._h, mode, max_steps, time_limit, 1 if sync else 0, C.byref(done))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, bool(done.value)
+
+    def download(self):
+        """-> (succ [B,n], obj [B], [stats])"""
+        n = self.inst.n
+        succ = np.zeros((self.B, n), dtype=np.int32)
+        obj = np.zeros(self.B, dtype=np.float64)
+        st = (Stats * self.B)()
+        _check(lib().tsp_dev_tours_download(self._h, _i(succ), 1, n, _d(obj), st))
+        return succ, obj, [s.as_dict() for s in st]
+
+    def time_scan(self, reps=20):
+        """-> (mean kernel ms, evals per launch) for the BEST-mode sweep kernel"""
+        ms = C.c_float(0)
+        ev = C.c_int64(0)
+        _check(lib().tsp_dev_tours_time_scan(self._h, reps, C.byref(ms), C.byref(ev)))
+        return ms.value, ev.value
+
+    def best(self, true_cost=True):
+        """-> (cost, tour index) minimum over the handle's tours"""
+        p = C.c_int64(0)
+        _check(lib().tsp_dev_tours_best(self._h, 1 if true_cost else 0, C.byref(p)))
+        return p.value >> 24, p.value & 0xFFFFFF, p.value
