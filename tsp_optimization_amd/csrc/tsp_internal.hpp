@@ -14,22 +14,6 @@
 
 namespace tsp {
 
-// Per-node record, one array of n per tour, indexed by NODE id (the reference scans pairs in
-// node-id order, src/heuristics.c:452-454).  48 bytes = three 16-byte loads per lane; a row's
-// record is wave-uniform and comes through the scalar cache.
-//   x, y    : this node's coordinates (static; lat/lon radians for GEO)
-//   xs, ys  : coordinates of succ(node)                    } rewritten by the apply kernel for
-//   ds      : calc_dist(node, succ(node))                  } the nodes a move touches
-//   succ    : succ(node), for the adjacency skip rules (heuristics.c:471, tabusearch.c:134)
-struct alignas(16) Rec {
-    double x, y;
-    double xs, ys;
-    double ds;
-    int succ;
-    int pad;
-};
-static_assert(sizeof(Rec) == 48, "Rec must be 48 bytes");
-
 // One scan block's candidate.  i < 0 means "none".
 struct alignas(16) Partial {
     double delta;
@@ -86,10 +70,14 @@ struct tsp_dev_tours {
     // device
     int *d_order = nullptr;          // B x n : node at tour position p
     int *d_pos = nullptr;            // B x n : position of node v
-    tsp::Rec *d_rec = nullptr;       // B x n
     tsp::TourState *d_state = nullptr;
     tsp::Partial *d_partial = nullptr;
     size_t partial_per_tour = 0;
+    int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
+    int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)
+    tsp::Partial *d_row_slot = nullptr;
+    int *d_row_evals = nullptr;
+    int max_tile_rows = 0;
     int *d_slot_evals = nullptr;     // per scan block: pairs evaluated (tabu runs only)
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;
@@ -97,9 +85,11 @@ struct tsp_dev_tours {
     // pinned host mirror of the states, for polling
     tsp::TourState *h_state = nullptr;
     // scan geometry
-    int first_rows_per_block = 4;
+    int first_rows_per_block = 8;
+    int first_min_rows = 8;
     int first_max_rows = 2048;
     int best_rows_per_block = 32;
+    int count_evals = 1;             // FIRST: keep the reference-equivalent evaluation counter
     // accumulated device time
     double device_ms = 0.0;
 };

@@ -1,9 +1,13 @@
 // two_opt_grid.hip -- GRID engine: 2-opt on tours resident in HBM, many workgroups per tour.
 //
-// One step = k_scan (evaluate a range of (i<j) node pairs against the current tour, one
-// candidate per block) + k_apply (one workgroup per tour: pick the winner, reverse the tour
-// segment, refresh the touched node records, advance the tour's control block).  The host only
-// queues steps and polls `done`; every decision of the reference's loops is taken on the device:
+// Tour state in HBM is two int arrays per tour, order[p] (node at tour position p) and pos[v]
+// (position of node v); succ(v) = order[pos[v]+1].  Coordinates are per instance.
+//
+// One step = ONE launch of k_step: every block evaluates its tile of (i<j) node pairs against the
+// current tour and publishes one candidate; the block that arrives last (per-tour countdown
+// ticket) picks the winner, reverses the tour segment and advances the tour's control block for
+// the next launch.  The host only queues steps and polls `done`; every decision of the
+// reference's loops is taken on the device:
 //   FIRST  = alg_2opt       (src/heuristics.c:438-502): first improving pair after the cursor in
 //            (i<j) order, applied at once, scan resumes right after it; stop after a sweep that
 //            did not lower obj_best (:492).
@@ -12,213 +16,120 @@
 //            recomputed as a sum over edges in node order (:168-172).
 //
 // The pair (i,j) always denotes removing (i,succ i) and (j,succ j) and reversing the FORWARD path
-// succ(i)..j (src/utility.c:708-717).  Tours are kept as order[]/pos[] arrays; the reversed path
-// is the cyclic position range pos[i]+1 .. pos[j], so orientation is preserved by construction.
-#include "tsp_internal.hpp"
+// succ(i)..j (src/utility.c:708-717): that path is the cyclic position range pos[i]+1 .. pos[j],
+// so reversing exactly that range keeps succ() identical to the reference's after every move.
+#include "two_opt_common.hpp"
+
+#include <algorithm>
+#include <time.h>
 
 #pragma clang fp contract(off)
 
 namespace tsp {
 
-using u64 = unsigned long long;
-constexpr u64 kNoKey = ~0ull;
+constexpr int kMaxRowsPerBlock = 64;
 
-__device__ __forceinline__ u64 make_key(int i, int j) {
-    return i < 0 ? kNoKey : (((u64)(unsigned)i << 32) | (u64)(unsigned)j);
-}
+// Diagnostic build only (-DTSP_STAMPS): 100 MHz wall-clock stamps of the last block of each step,
+// accumulated into a buffer nothing else reads (cdna_hip_programming.md section 7, in-kernel stamps).
+#ifdef TSP_STAMPS
+__device__ unsigned long long g_stamp_sum[16];
+__device__ unsigned long long g_stamp_n;
+#define TSP_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+#else
+#define TSP_STAMP(k) do { } while (0)
+#endif
 
-// (delta, key) lexicographic minimum == "first pair in scan order among the minimal deltas"
-__device__ __forceinline__ bool better(double d1, u64 k1, double d2, u64 k2) {
-    return d1 < d2 || (d1 == d2 && k1 < k2);
-}
-
-template <bool BY_DELTA>
-__device__ __forceinline__ void wave_argmin(double &d, u64 &k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double od = __shfl_xor(d, off);
-        const u64 ok = __shfl_xor(k, off);
-        const bool take = BY_DELTA ? better(od, ok, d, k) : (ok < k);
-        if (take) { d = od; k = ok; }
-    }
-}
-
-// number of pairs (r,c), r<c, that precede or equal (i,j) in lexicographic order
-__device__ __forceinline__ long long pair_rank(long long i, long long j, long long n) {
-    return i * (n - 1) - i * (i - 1) / 2 + (j - i);
-}
-
-// src/utility.c:17-30 for i != j
-__device__ __forceinline__ long long udir_pos(int i, int j, int n) {
-    if (i > j) { const int t = i; i = j; j = t; }
-    return (long long)i * n + j - ((long long)(i + 1) * (i + 2)) / 2;
-}
-
-// src/tabusearch.c:83-92, including the lazy clearing write.  Within one call iter and tenure
-// are constant, so concurrent clears of an expired stamp all store 0: a benign race.
-__device__ __forceinline__ bool stamp_is_tabu(int *stamp, int iter, int tenure) {
-    if (iter < 0 || tenure < 0) return false;
-    const int v = *stamp;
-    if (v == 0) return false;
-    if (iter - v > tenure) { *stamp = 0; return false; }
-    return true;
-}
-
-// ---- build pos[] and rec[] from order[] ---------------------------------------------------
-template <int WT, bool INT>
-__global__ void k_build(const double2 *__restrict__ coord, const int *__restrict__ orders,
-                        int *__restrict__ poss, Rec *__restrict__ recs, int n) {
-    const int tour = blockIdx.y;
+__global__ void k_build_pos(const int *__restrict__ orders, int *__restrict__ poss, int n) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const int *order = orders + (size_t)tour * n;
-    const int v = order[p];
-    const int w = order[p + 1 == n ? 0 : p + 1];
-    const double2 cv = coord[v], cw = coord[w];
-    poss[(size_t)tour * n + v] = p;
-    Rec r;
-    r.x = cv.x; r.y = cv.y; r.xs = cw.x; r.ys = cw.y;
-    r.ds = dist_xy<WT, INT>(cv.x, cv.y, cw.x, cw.y);
-    r.succ = w; r.pad = 0;
-    recs[(size_t)tour * n + v] = r;
+    const size_t base = (size_t)blockIdx.y * n;
+    poss[base + orders[base + p]] = p;
 }
 
-// ---- scan ---------------------------------------------------------------------------------
-// Block (bx, by, tour): rows r0 .. r0+rows_per_block of the tour's active row range, columns
-// bx*256*RJ .. +256*RJ.  Lanes own columns (coalesced 48-byte record loads, held in registers
-// for all rows of the block); the row record is wave-uniform (scalar loads).
-template <int WT, bool INT, int MODE, int RJ, bool TABU>
-__global__ __launch_bounds__(kScanThreads) void k_scan(const Rec *__restrict__ recs,
-                                                       const TourState *__restrict__ states,
-                                                       Partial *__restrict__ partials, int n,
-                                                       int rows_per_block, size_t partial_per_tour,
-                                                       int *__restrict__ tabu, int iter, int tenure,
-                                                       int *__restrict__ slot_evals) {
-    const int tour = blockIdx.z;
-    const TourState *st = states + tour;
-    if (st->done) return;
-    int row_lo = 0, row_hi = n - 1, ci = -1, cj = -1;
+// ---- in-launch hand-off of the block candidates ---------------------------------------------
+// Producer (lane 0 of each block): two 8-byte write-through (sc1) stores, drain, then one relaxed
+// agent-scope countdown on the tour's ticket.  Consumer (the block whose decrement returned 1):
+// sc1 loads after the block barrier that the decrementing wave joins.  Every slot is written once
+// and read once per launch and launches are separated by kernel boundaries, so no stale copy of a
+// slot can sit in the reader's caches (cdna_hip_programming.md G16 / MI355X_MICROARCH.md
+// "Valid forms", first row).  order/pos/state are only written by the last block, after every
+// other block of the tour has finished, and are next read in the following launch.
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gi32 = __attribute__((address_space(1))) int;
+
+__device__ __forceinline__ void publish_partial(Partial *slot, double delta, int i, int j) {
+    gu64 *g = (gu64 *)slot;
+    __hip_atomic_store(g, (u64)__double_as_longlong(delta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((u64)(unsigned)j << 32) | (u64)(unsigned)i, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void read_partial(const Partial *slot, double &delta, int &i, int &j) {
+    gu64 *g = (gu64 *)slot;
+    const u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    delta = __longlong_as_double((long long)a);
+    i = (int)(b & 0xffffffffu);
+    j = (int)(b >> 32);
+}
+
+// Blocks of a step that own at least one column above their first row (the others return at
+// once and take no ticket).  Block (bx, by) is skipped iff bx < (r0(by) + 1) / TJ.
+__device__ __forceinline__ int skipped_in_tile_row(int r0, int gx, int TJ) { return min(gx, (r0 + 1) / TJ); }
+
+__device__ __forceinline__ int count_active_blocks(int row_lo, int row_hi, int rpb, int gx, int gy, int TJ,
+                                                   int *scratch) {
+    const int tile_rows = min((row_hi - row_lo + rpb - 1) / rpb, gy);
+    int c = 0;
+    for (int by = threadIdx.x; by < tile_rows; by += (int)blockDim.x)
+        c += gx - skipped_in_tile_row(row_lo + by * rpb, gx, TJ);
+    return block_sum<int>(c, scratch);
+}
+
+template <int MODE>
+__device__ __forceinline__ void active_rows(const TourState *st, int n, int &row_lo, int &row_hi) {
+    row_lo = 0; row_hi = n - 1;
     if constexpr (MODE == TSP_2OPT_FIRST) {
-        ci = st->ci; cj = st->cj;
-        row_lo = ci;
-        row_hi = min(ci + st->chunk_rows, n - 1);
-    }
-    const int r0 = row_lo + blockIdx.y * rows_per_block;
-    if (r0 >= row_hi) return;  // beyond the active chunk: no slot is read for this block
-    const int r1 = min(r0 + rows_per_block, row_hi);
-    const int c0 = blockIdx.x * (kScanThreads * RJ);
-    Partial *slot = partials + (size_t)tour * partial_per_tour + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const int tid = threadIdx.x;
-    if (c0 + kScanThreads * RJ - 1 <= r0) {  // every column <= every row: nothing with j > i
-        if (tid == 0) {
-            Partial p; p.delta = 0.0; p.i = -1; p.j = -1; *slot = p;
-            if constexpr (TABU) slot_evals[slot - partials] = 0;
-        }
-        return;
-    }
-    const Rec *rec = recs + (size_t)tour * n;
-    int n_eval = 0;  // TABU: pairs that reach the delta expression (tabusearch.c:150)
-
-    int jc[RJ];
-    Rec rj[RJ];
-#pragma unroll
-    for (int k = 0; k < RJ; ++k) {
-        jc[k] = c0 + tid + k * kScanThreads;
-        rj[k] = rec[min(jc[k], n - 1)];
-        if (jc[k] >= n) jc[k] = -1;  // never > i
-    }
-
-    double bd = 0.0;
-    int bi = -1, bj = -1;
-    for (int i = r0; i < r1; ++i) {
-        const Rec ri = rec[i];
-#pragma unroll
-        for (int k = 0; k < RJ; ++k) {
-            const int j = jc[k];
-            bool ok = j > i && j != ri.succ && rj[k].succ != i;  // heuristics.c:471 / tabusearch.c:134
-            if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj) && bi < 0;
-            if constexpr (TABU) {
-                if (ok) {
-                    const int a1 = ri.succ, b1 = rj[k].succ;
-                    if (stamp_is_tabu(tabu + udir_pos(i, j, n), iter, tenure) ||
-                        stamp_is_tabu(tabu + udir_pos(i, a1, n), iter, tenure) ||
-                        stamp_is_tabu(tabu + udir_pos(j, b1, n), iter, tenure) ||
-                        stamp_is_tabu(tabu + udir_pos(i, b1, n), iter, tenure))
-                        ok = false;  // tabusearch.c:137-149
-                }
-                n_eval += ok ? 1 : 0;
-            }
-            // heuristics.c:474 / tabusearch.c:150, same association: ((d(a,b)+d(a1,b1))-d(a,a1))-d(b,b1)
-            const double delta = dist_xy<WT, INT>(ri.x, ri.y, rj[k].x, rj[k].y) +
-                                 dist_xy<WT, INT>(ri.xs, ri.ys, rj[k].xs, rj[k].ys) - ri.ds - rj[k].ds;
-            if constexpr (MODE == TSP_2OPT_FIRST) {
-                if (ok && delta < 0) { bd = delta; bi = i; bj = j; }
-            } else {
-                if (ok && delta < bd) { bd = delta; bi = i; bj = j; }
-            }
-        }
-        if constexpr (MODE == TSP_2OPT_FIRST) {
-            if (__any(bi >= 0)) break;  // later rows only hold later pairs
-        }
-    }
-
-    u64 key = make_key(bi, bj);
-    wave_argmin<MODE == TSP_2OPT_BEST>(bd, key);
-    __shared__ double s_d[kScanThreads / 64];
-    __shared__ u64 s_k[kScanThreads / 64];
-    if ((tid & 63) == 0) { s_d[tid >> 6] = bd; s_k[tid >> 6] = key; }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int w = 1; w < kScanThreads / 64; ++w) {
-            const bool take = (MODE == TSP_2OPT_BEST) ? better(s_d[w], s_k[w], bd, key) : (s_k[w] < key);
-            if (take) { bd = s_d[w]; key = s_k[w]; }
-        }
-        Partial p;
-        p.delta = bd;
-        p.i = key == kNoKey ? -1 : (int)(key >> 32);
-        p.j = key == kNoKey ? -1 : (int)(key & 0xffffffffu);
-        *slot = p;
-    }
-    if constexpr (TABU) {
-        __shared__ int s_cnt;
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) n_eval += __shfl_xor(n_eval, off);
-        if ((tid & 63) == 0) atomicAdd(&s_cnt, n_eval);
-        __syncthreads();
-        if (tid == 0) slot_evals[slot - partials] = s_cnt;
+        row_lo = st->ci;
+        row_hi = min(st->ci + st->chunk_rows, n - 1);
     }
 }
 
-// ---- apply --------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T block_sum(T v, T *scratch /* >= 16 */) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    const int tid = threadIdx.x;
-    __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
-    __syncthreads();
-    T tot = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += scratch[w];
-    return tot;
+// Arms the tickets for the first step of a run (later steps are armed by the apply).
+// FIRST: per-tour countdown of the active blocks.  BEST: count-up tickets (per tile row, then per
+// tour) start at zero.
+template <int MODE>
+__global__ __launch_bounds__(kScanThreads) void k_arm(const TourState *__restrict__ states, int *__restrict__ tickets,
+                                                      int *__restrict__ row_tickets, int max_tile_rows,
+                                                      int n, int rpb, int gx, int gy, int TJ) {
+    __shared__ int s_i[kScanThreads / 64];
+    const TourState *st = states + blockIdx.x;
+    if constexpr (MODE == TSP_2OPT_BEST) {
+        for (int k = threadIdx.x; k < max_tile_rows; k += kScanThreads) row_tickets[(size_t)blockIdx.x * max_tile_rows + k] = 0;
+        if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
+    } else {
+        int row_lo, row_hi;
+        active_rows<MODE>(st, n, row_lo, row_hi);
+        const int c = count_active_blocks(row_lo, row_hi, rpb, gx, gy, TJ, s_i);
+        if (threadIdx.x == 0) tickets[blockIdx.x] = st->done ? 0 : c;
+    }
 }
 
+// ---- tour cost ----------------------------------------------------------------------------
 // Sum over nodes of d(v, succ v) in node order (tabusearch.c:168-172), by one whole block.
-template <bool INT>
-__device__ __forceinline__ double tour_cost_block(const Rec *rec, int n, double *s_d /*>=16*/, double *s_chunk /*4096*/) {
+template <int WT, bool INT>
+__device__ __forceinline__ double tour_cost_block(const double2 *coord, const int *order, const int *pos, int n,
+                                                  double *s_d /*>=16*/, double *s_chunk /*4096 unless INT*/) {
     const int tid = threadIdx.x;
-    if constexpr (INT) {  // integer-valued terms: any order is exact
+    if constexpr (INT || WT == WT_CEIL_2D) {  // integer-valued terms: any order is exact
         double c = 0.0;
-        for (int v = tid; v < n; v += (int)blockDim.x) c += rec[v].ds;
+        for (int v = tid; v < n; v += (int)blockDim.x) c += load_node<WT, INT>(coord, order, pos, n, v).ds;
         return block_sum<double>(c, s_d);
-    } else {              // same sequential order as the reference, staged through LDS
+    } else {  // same sequential order as the reference, staged through LDS
         double acc = 0.0;
         for (int base = 0; base < n; base += 4096) {
             __syncthreads();
-            for (int t = tid; t < 4096 && base + t < n; t += (int)blockDim.x) s_chunk[t] = rec[base + t].ds;
+            for (int t = tid; t < 4096 && base + t < n; t += (int)blockDim.x)
+                s_chunk[t] = load_node<WT, INT>(coord, order, pos, n, base + t).ds;
             __syncthreads();
             if (tid == 0) {
                 const int m = min(4096, n - base);
@@ -232,193 +143,371 @@ __device__ __forceinline__ double tour_cost_block(const Rec *rec, int n, double 
     }
 }
 
-// obj = recomputed cost, for BEST runs that stop before the local optimum (time limit)
-template <bool INT>
-__global__ __launch_bounds__(kApplyThreads) void k_tour_cost(const Rec *__restrict__ recs, TourState *__restrict__ states, int n) {
+// out[b] = recomputed cost of tour b (BEST runs that stop early; multi-start "true cost")
+template <int WT, bool INT>
+__global__ __launch_bounds__(kApplyThreads) void k_tour_cost(const double2 *__restrict__ coord,
+                                                             const int *__restrict__ orders,
+                                                             const int *__restrict__ poss, int n,
+                                                             double *__restrict__ out, size_t out_stride_bytes) {
     __shared__ double s_d[kApplyThreads / 64];
-    __shared__ double s_chunk[INT ? 1 : 4096];
-    const double c = tour_cost_block<INT>(recs + (size_t)blockIdx.x * n, n, s_d, s_chunk);
-    if (threadIdx.x == 0) states[blockIdx.x].obj = c;
+    __shared__ double s_chunk[(INT || WT == WT_CEIL_2D) ? 1 : 4096];
+    const size_t base = (size_t)blockIdx.x * n;
+    const double c = tour_cost_block<WT, INT>(coord, orders + base, poss + base, n, s_d, s_chunk);
+    if (threadIdx.x == 0)
+        *reinterpret_cast<double *>(reinterpret_cast<char *>(out) + blockIdx.x * out_stride_bytes) = c;
 }
 
-template <int WT, bool INT, int MODE>
-__global__ __launch_bounds__(kApplyThreads) void k_apply(Rec *__restrict__ recs, int *__restrict__ orders,
-                                                         int *__restrict__ poss, TourState *__restrict__ states,
-                                                         const Partial *__restrict__ partials, int n,
-                                                         int rows_per_block, int scan_gx, int scan_gy,
-                                                         size_t partial_per_tour, int first_min_rows,
-                                                         int first_max_rows, int count_evals,
-                                                         const int *__restrict__ slot_evals) {
-    const int tour = blockIdx.x;
-    TourState *st = states + tour;
-    if (st->done) return;
+// ---- apply: executed by the last block of a tour's step ------------------------------------
+struct StepArgs {
+    const double2 *coord;
+    int *orders;
+    int *poss;
+    TourState *states;
+    Partial *partials;
+    int *tickets;      // per tour
+    int *row_tickets;  // per tour x tile row (BEST: two-level hand-off)
+    Partial *row_slots; // per tour x tile row
+    int *row_evals;    // per tour x tile row (tabu runs)
+    int max_tile_rows;
+    int *slot_evals;   // tabu runs only
+    int *tabu;
+    size_t partial_per_tour;
+    int n, rows_per_block, first_min_rows, first_max_rows, count_evals, iter, tenure;
+};
+
+template <int WT, bool INT, int MODE, int RJ, bool TABU>
+__device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_lo, int row_hi
+#ifdef TSP_STAMPS
+                                           , unsigned long long *stamps
+#endif
+) {
+    constexpr int TJ = kScanThreads * RJ;
+    const int n = a.n, rpb = a.rows_per_block;
+    const int gx = gridDim.x, gy = gridDim.y;
+    TourState *st = a.states + tour;
     const int tid = threadIdx.x;
-    Rec *rec = recs + (size_t)tour * n;
-    int *order = orders + (size_t)tour * n;
-    int *pos = poss + (size_t)tour * n;
-    const Partial *part = partials + (size_t)tour * partial_per_tour;
+    int *order = a.orders + (size_t)tour * n;
+    int *pos = a.poss + (size_t)tour * n;
+    const Partial *part = a.partials + (size_t)tour * a.partial_per_tour;
 
-    __shared__ double s_d[kApplyThreads / 64];
-    __shared__ u64 s_k[kApplyThreads / 64];
-    __shared__ long long s_ll[kApplyThreads / 64];
-    __shared__ double s_delta;
-    __shared__ int s_i, s_j, s_pa, s_pb;
+    __shared__ double s_d[kScanThreads / 64];
+    __shared__ u64 s_k[kScanThreads / 64];
+    __shared__ long long s_ll[kScanThreads / 64];
+    __shared__ int s_i32[kScanThreads / 64];
 
-    int row_lo = 0, row_hi = n - 1, ci = 0, cj = 0;
-    if constexpr (MODE == TSP_2OPT_FIRST) {
-        ci = st->ci; cj = st->cj;
-        row_lo = ci;
-        row_hi = min(ci + st->chunk_rows, n - 1);
-    }
-    int tile_rows = (row_hi - row_lo + rows_per_block - 1) / rows_per_block;
-    tile_rows = min(tile_rows, scan_gy);
-    const int nslots = tile_rows * scan_gx;
+    constexpr bool HIER = MODE == TSP_2OPT_BEST;  // BEST: one pre-reduced candidate per tile row
+    const int ci = MODE == TSP_2OPT_FIRST ? st->ci : 0, cj = MODE == TSP_2OPT_FIRST ? st->cj : 0;
+    const int tile_rows = min((row_hi - row_lo + rpb - 1) / rpb, gy);
+    const int nslots = HIER ? tile_rows : tile_rows * gx;
+    if constexpr (HIER) part = a.row_slots + (size_t)tour * a.max_tile_rows;
 
-    // 1. winner over the scan blocks
+    // 1. winner over the blocks that published a candidate (loads batched: they are sc1 loads
+    //    that go to memory, so eight slots per lane are kept in flight)
     double bd = 0.0;
     u64 key = kNoKey;
-    for (int s = tid; s < nslots; s += kApplyThreads) {
-        const Partial p = part[s];
-        const u64 k = make_key(p.i, p.j);
-        const bool take = (MODE == TSP_2OPT_BEST) ? better(p.delta, k, bd, key) : (k < key);
-        if (take) { bd = p.delta; key = k; }
+    long long tabu_evals = 0;
+    constexpr int PU = 8;
+    for (int s0 = tid; s0 < nslots; s0 += PU * kScanThreads) {
+        double pd[PU]; int pi[PU], pj[PU]; bool live[PU];
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const int s = s0 + k * kScanThreads;
+            const int by = s / gx, bx = s - by * gx;
+            live[k] = s < nslots && (HIER || bx >= skipped_in_tile_row(row_lo + by * rpb, gx, TJ));
+            pd[k] = 0.0; pi[k] = -1; pj[k] = -1;
+            if (live[k]) read_partial(part + s, pd[k], pi[k], pj[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < PU; ++k) {
+            const u64 kk = make_key(pi[k], pj[k]);
+            const bool take = live[k] && ((MODE == TSP_2OPT_BEST) ? better(pd[k], kk, bd, key) : (kk < key));
+            if (take) { bd = pd[k]; key = kk; }
+            if constexpr (TABU) {
+                if (live[k])
+                    tabu_evals += __hip_atomic_load(
+                        (gi32 *)(a.row_evals + (size_t)tour * a.max_tile_rows + s0 + k * kScanThreads),
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    wave_argmin<MODE == TSP_2OPT_BEST>(bd, key);
-    if ((tid & 63) == 0) { s_d[tid >> 6] = bd; s_k[tid >> 6] = key; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < kApplyThreads / 64; ++w) {
-            const bool take = (MODE == TSP_2OPT_BEST) ? better(s_d[w], s_k[w], bd, key) : (s_k[w] < key);
-            if (take) { bd = s_d[w]; key = s_k[w]; }
-        }
-        int wi = -1, wj = -1;
-        if (key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0)) {
-            wi = (int)(key >> 32); wj = (int)(key & 0xffffffffu);
-        }
-        s_i = wi; s_j = wj;
-        if (wi >= 0) {
-            s_pa = pos[wi]; s_pb = pos[wj];
-            const Rec ra = rec[wi], rb = rec[wj];
-            s_delta = dist_xy<WT, INT>(ra.x, ra.y, rb.x, rb.y) + dist_xy<WT, INT>(ra.xs, ra.ys, rb.xs, rb.ys) -
-                      ra.ds - rb.ds;
-        }
-    }
-    __syncthreads();
-    const int wi = s_i, wj = s_j;
-    const bool found = wi >= 0;
+    block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
+    TSP_STAMP(6);
+    if constexpr (TABU) tabu_evals = block_sum<long long>(tabu_evals, s_ll);
+    const bool found = key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0);
+    const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
+    int pa = 0, pb = 0;
+    if (found) { pa = pos[wi]; pb = pos[wj]; }
 
-    // 2. FIRST: how many of the pairs between the old and the new cursor the reference would have
-    //    skipped as adjacent (counted on the tour the scan saw, i.e. before the move)
+    // 2. FIRST: how many pairs between the old and the new cursor the reference would have skipped
+    //    as adjacent (heuristics.c:471), on the tour the scan saw.  Row r's adjacent columns are
+    //    succ(r) and pred(r), when they are > r.
     long long adj = 0;
     int ni = wi, nj = wj;  // new cursor
     if constexpr (MODE == TSP_2OPT_FIRST) {
         if (!found) { ni = row_hi - 1; nj = n - 1; }
-        if (count_evals) {
-            const u64 lo = ((u64)(unsigned)ci << 32) | (unsigned)cj, hi = ((u64)(unsigned)ni << 32) | (unsigned)nj;
+        if (a.count_evals) {
+            const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
             long long c = 0;
-            for (int v = tid; v < n; v += kApplyThreads) {
-                const int s = rec[v].succ;
-                const u64 k = ((u64)(unsigned)min(v, s) << 32) | (unsigned)max(v, s);
-                c += (k > lo && k <= hi) ? 1 : 0;
+            for (int r = ci + tid; r <= ni; r += kScanThreads) {
+                const int p = pos[r];
+                const int s = order[p + 1 == n ? 0 : p + 1], q = order[p == 0 ? n - 1 : p - 1];
+                const u64 ks = make_key(r, s), kq = make_key(r, q);
+                c += (s > r && ks > lo && ks <= hi) ? 1 : 0;
+                c += (q > r && kq > lo && kq <= hi) ? 1 : 0;
             }
             adj = block_sum<long long>(c, s_ll);
         }
     }
+    __syncthreads();  // every read of the old order/pos is done
+    TSP_STAMP(7);
 
-    // 3. the move: reverse positions pa+1 .. pb (cyclic), then refresh the records of pa .. pb
+    // 3. the move: reverse positions pa+1 .. pb (cyclic)
     int L = 0;
     if (found) {
-        const int pa = s_pa, pb = s_pb;
         L = pb - pa; if (L < 0) L += n;
         const int half = L >> 1;
-        for (int t = tid; t < half; t += kApplyThreads) {
-            int p = pa + 1 + t; if (p >= n) p -= n;
-            int q = pb - t; if (q < 0) q += n;
-            const int u = order[p], w = order[q];
-            order[p] = w; order[q] = u;
-            pos[w] = p; pos[u] = q;
-        }
-        __syncthreads();
-        for (int t = tid; t <= L; t += kApplyThreads) {
-            int p = pa + t; if (p >= n) p -= n;
-            const int q = p + 1 == n ? 0 : p + 1;
-            const int v = order[p], w = order[q];
-            const double vx = rec[v].x, vy = rec[v].y, wx = rec[w].x, wy = rec[w].y;
-            rec[v].xs = wx; rec[v].ys = wy;
-            rec[v].ds = dist_xy<WT, INT>(vx, vy, wx, wy);
-            rec[v].succ = w;
-        }
-    }
-
-    // 4. BEST at the local optimum: cost = sum over nodes of d(v, succ v), node order (tabusearch.c:168-172)
-    double final_cost = 0.0;
-    long long tabu_evals = -1;
-    if constexpr (MODE == TSP_2OPT_BEST) {
-        if (slot_evals) {  // tabu list active: the scan blocks counted what reached the delta expression
-            long long c = 0;
-            for (int s = tid; s < nslots; s += kApplyThreads) c += slot_evals[(size_t)tour * partial_per_tour + s];
-            tabu_evals = block_sum<long long>(c, s_ll);
-        }
-        if (!found) {
-            __shared__ double s_chunk[INT ? 1 : 4096];
-            final_cost = tour_cost_block<INT>(rec, n, s_d, s_chunk);
-        }
-    }
-
-    // 5. control block
-    if (tid == 0) {
-        st->steps += 1;
-        if constexpr (MODE == TSP_2OPT_BEST) {
-            st->sweeps += 1;
-            st->evals += tabu_evals >= 0 ? tabu_evals : (long long)n * (n - 1) / 2 - n;  // every non-adjacent pair (n >= 4)
-            st->pairs_scanned += (long long)n * (n - 1) / 2;
-            if (found) { st->moves += 1; st->reversed += L - 1; }
-            else { st->done = 1; st->obj = final_cost; }
-        } else {
-            const long long r_old = pair_rank(ci, cj, n);
-            const long long r_end = pair_rank(row_hi - 1, n - 1, n);
-            st->pairs_scanned += r_end - r_old;
-            st->evals += pair_rank(ni, nj, n) - r_old - adj;
-            if (found) {
-                st->obj += s_delta;                    // heuristics.c:486
-                st->moves += 1;
-                st->reversed += L - 1;         // successors rewritten by reverse_path's walk (utility.c:710-717)
-                st->ci = wi; st->cj = wj;
-                st->chunk_rows = first_min_rows;
-            } else {
-                st->chunk_rows = min(st->chunk_rows * 2, first_max_rows);
-                if (row_hi >= n - 1) {                 // sweep complete
-                    st->sweeps += 1;
-                    if (st->obj >= st->seen_cost) st->done = 1;   // heuristics.c:492
-                    else { st->seen_cost = st->obj; st->ci = 0; st->cj = 0; }
-                } else {
-                    st->ci = row_hi - 1; st->cj = n - 1;
+        constexpr int U = 8;
+        for (int t0 = tid; t0 < half; t0 += U * kScanThreads) {
+            int p[U], q[U], u[U], w[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int t = t0 + k * kScanThreads;
+                p[k] = pa + 1 + t; if (p[k] >= n) p[k] -= n;
+                q[k] = pb - t; if (q[k] < 0) q[k] += n;
+                u[k] = 0; w[k] = 0;
+                if (t < half) { u[k] = order[p[k]]; w[k] = order[q[k]]; }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (t0 + k * kScanThreads < half) {
+                    order[p[k]] = w[k]; order[q[k]] = u[k];
+                    pos[w[k]] = p[k]; pos[u[k]] = q[k];
                 }
             }
         }
     }
+
+    TSP_STAMP(8);
+    // 4. BEST at the local optimum: recomputed cost
+    double final_cost = 0.0;
+    if constexpr (MODE == TSP_2OPT_BEST) {
+        if (!found) {
+            __shared__ double s_chunk[(INT || WT == WT_CEIL_2D) ? 1 : 4096];
+            final_cost = tour_cost_block<WT, INT>(a.coord, order, pos, n, s_d, s_chunk);
+        }
+    }
+
+    // 5. next cursor / chunk, and the ticket for the next launch
+    int done = 0, n_ci = 0, n_cj = 0, n_chunk = st->chunk_rows, sweep_end = 0;
+    double obj = st->obj, seen = st->seen_cost;
+    if constexpr (MODE == TSP_2OPT_BEST) {
+        if (found) { obj = st->obj; } else { done = 1; obj = final_cost; }
+    } else {
+        if (found) {
+            obj += bd;                               // heuristics.c:486
+            n_ci = wi; n_cj = wj; n_chunk = a.first_min_rows;
+        } else {
+            n_chunk = min(st->chunk_rows * 2, a.first_max_rows);
+            if (row_hi >= n - 1) {                   // sweep complete
+                sweep_end = 1;
+                if (obj >= seen) done = 1;           // heuristics.c:492
+                else { seen = obj; n_ci = 0; n_cj = 0; }
+            } else { n_ci = row_hi - 1; n_cj = n - 1; }
+        }
+    }
+    int next_lo = 0, next_hi = n - 1;
+    if constexpr (MODE == TSP_2OPT_FIRST) { next_lo = n_ci; next_hi = min(n_ci + n_chunk, n - 1); }
+    int next_active = 0;
+    if constexpr (HIER) {   // count-up tickets back to zero for the next launch
+        for (int k = tid; k < tile_rows; k += kScanThreads)
+            __hip_atomic_store((gi32 *)(a.row_tickets + (size_t)tour * a.max_tile_rows + k), 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        next_active = count_active_blocks(next_lo, next_hi, rpb, gx, gy, TJ, s_i32);
+    }
+
+    if (tid == 0) {
+        st->steps += 1;
+        if constexpr (MODE == TSP_2OPT_BEST) {
+            st->sweeps += 1;
+            st->evals += TABU ? tabu_evals : (long long)n * (n - 1) / 2 - n;  // non-adjacent pairs (n >= 4)
+            st->pairs_scanned += (long long)n * (n - 1) / 2;
+            if (found) { st->moves += 1; st->reversed += L - 1; }
+        } else {
+            const long long r_old = pair_rank(ci, cj, n);
+            st->pairs_scanned += pair_rank(row_hi - 1, n - 1, n) - r_old;
+            st->evals += pair_rank(ni, nj, n) - r_old - adj;
+            if (found) { st->moves += 1; st->reversed += L - 1; }   // successors rewritten by utility.c:710-717
+            st->sweeps += sweep_end;
+            st->ci = n_ci; st->cj = n_cj; st->chunk_rows = n_chunk; st->seen_cost = seen;
+        }
+        st->obj = obj;
+        st->done = done;
+        if constexpr (!HIER)
+            __hip_atomic_store((gi32 *)(a.tickets + tour), done ? 0 : next_active, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TSP_STAMPS
+        stamps[9] = wall_clock64();
+        for (int k = 1; k < 10; ++k) atomicAdd(&g_stamp_sum[k], stamps[k] - stamps[k - 1]);
+        atomicAdd(&g_stamp_n, 1ull);
+#endif
+    }
 }
 
-// packed (cost, tour) minimum over the tours of one handle
-template <int WT, bool INT>
-__global__ __launch_bounds__(kApplyThreads) void k_best_tour(const Rec *__restrict__ recs,
-                                                             const TourState *__restrict__ states, int n, int B,
-                                                             int true_cost, long long *__restrict__ out) {
-    __shared__ double s_d[kApplyThreads / 64];
-    long long best = 0x7fffffffffffffffLL;
-    for (int t = 0; t < B; ++t) {
-        double c;
-        if (true_cost) {
-            double acc = 0.0;
-            for (int v = threadIdx.x; v < n; v += kApplyThreads) acc += recs[(size_t)t * n + v].ds;
-            c = block_sum<double>(acc, s_d);
-        } else {
-            c = states[t].obj;
-        }
-        const long long packed = ((long long)c << 24) | (long long)t;
-        best = packed < best ? packed : best;
+// ---- step kernel ------------------------------------------------------------------------------
+// Block (bx, by, tour): rows r0 .. r0+rows_per_block of the tour's active row range, columns
+// bx*256*RJ .. +256*RJ.  Prologue: the block derives the NodeRec of its rows (into LDS) and of its
+// columns (RJ per lane, registers) from order/pos/coord -- three dependent loads and one sqrt per
+// node, amortised over rows x columns evaluations.  Main loop: lanes own columns, the row record
+// is a wave-uniform LDS broadcast; ~70 fp64 instructions per evaluation, no memory traffic.
+template <int WT, bool INT, int MODE, int RJ, bool TABU>
+__global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
+    constexpr int TJ = kScanThreads * RJ;
+#ifdef TSP_STAMPS
+    __shared__ unsigned long long stamps[16];
+#endif
+    TSP_STAMP(0);
+    const int tour = blockIdx.z;
+    const int n = a.n;
+    const TourState *st = a.states + tour;
+    if (st->done) return;
+    int row_lo, row_hi, ci = -1, cj = -1;
+    active_rows<MODE>(st, n, row_lo, row_hi);
+    if constexpr (MODE == TSP_2OPT_FIRST) { ci = st->ci; cj = st->cj; }
+    const int r0 = row_lo + blockIdx.y * a.rows_per_block;
+    if (r0 >= row_hi) return;                 // beyond the active chunk
+    const int r1 = min(r0 + a.rows_per_block, row_hi);
+    const int c0 = blockIdx.x * TJ;
+    if (c0 + TJ - 1 <= r0) return;            // every column <= every row: nothing with j > i, no ticket
+    const size_t slot_idx = (size_t)tour * a.partial_per_tour + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int *order = a.orders + (size_t)tour * n;
+    const int *pos = a.poss + (size_t)tour * n;
+
+    __shared__ NodeRec s_rows[kMaxRowsPerBlock];
+    if (tid < r1 - r0) s_rows[tid] = load_node<WT, INT>(a.coord, order, pos, n, r0 + tid);
+    int jc[RJ];
+    NodeRec rj[RJ];
+#pragma unroll
+    for (int k = 0; k < RJ; ++k) {
+        jc[k] = c0 + tid + k * kScanThreads;
+        rj[k] = load_node<WT, INT>(a.coord, order, pos, n, min(jc[k], n - 1));
+        if (jc[k] >= n) jc[k] = -1;  // never > i
     }
-    if (threadIdx.x == 0) *out = best;
+    __syncthreads();
+    TSP_STAMP(1);
+
+    double bd = 0.0;
+    int bi = -1, bj = -1;
+    int n_eval = 0;  // TABU: pairs that reach the delta expression (tabusearch.c:150)
+    // rows in groups of RU: RU x RJ independent delta evaluations per lane keep the fp64 pipe fed
+    // (the sqrt refinement is a long dependent chain); FIRST leaves after the group with a hit
+    constexpr int RU = (MODE == TSP_2OPT_FIRST) ? 4 : 1;
+    for (int ib = r0; ib < r1; ib += RU) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int i = min(ib + u, r1 - 1);
+            const bool row_ok = ib + u < r1;
+            const NodeRec ri = s_rows[i - r0];
+#pragma unroll
+            for (int k = 0; k < RJ; ++k) {
+                const int j = jc[k];
+                bool ok = row_ok && j > i && j != ri.succ && rj[k].succ != i;  // heuristics.c:471 / tabusearch.c:134
+                if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
+                if constexpr (TABU) {
+                    if (ok) {
+                        const int a1 = ri.succ, b1 = rj[k].succ;
+                        if (stamp_is_tabu(a.tabu + udir_pos(i, j, n), a.iter, a.tenure) ||
+                            stamp_is_tabu(a.tabu + udir_pos(i, a1, n), a.iter, a.tenure) ||
+                            stamp_is_tabu(a.tabu + udir_pos(j, b1, n), a.iter, a.tenure) ||
+                            stamp_is_tabu(a.tabu + udir_pos(i, b1, n), a.iter, a.tenure))
+                            ok = false;  // tabusearch.c:137-149
+                    }
+                    n_eval += ok ? 1 : 0;
+                }
+                const double delta = pair_delta<WT, INT>(ri, rj[k]);
+                if constexpr (MODE == TSP_2OPT_FIRST) {
+                    if (ok && delta < 0 && bi < 0) { bd = delta; bi = i; bj = j; }  // keep the first in (i, j) order
+                } else {
+                    if (ok && delta < bd) { bd = delta; bi = i; bj = j; }
+                }
+            }
+        }
+        if constexpr (MODE == TSP_2OPT_FIRST) {
+            if (__any(bi >= 0)) break;  // later rows only hold later pairs
+        }
+    }
+
+    u64 key = make_key(bi, bj);
+    __shared__ double s_d[kScanThreads / 64];
+    __shared__ u64 s_k[kScanThreads / 64];
+    __shared__ int s_cnt[kScanThreads / 64];
+    __shared__ int s_last;
+    TSP_STAMP(2);
+    block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
+    TSP_STAMP(3);
+    int tot_eval = 0;
+    if constexpr (TABU) tot_eval = block_sum<int>(n_eval, s_cnt);
+    constexpr bool HIER = MODE == TSP_2OPT_BEST;
+    const int skipped = skipped_in_tile_row(r0, gridDim.x, TJ);
+    if (tid == 0) {
+        publish_partial(a.partials + slot_idx, bd, key_i(key), key_j(key));
+        if constexpr (TABU)
+            __hip_atomic_store((gi32 *)(a.slot_evals + slot_idx), tot_eval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
+        TSP_STAMP(4);
+        if constexpr (HIER) {
+            const int old = __hip_atomic_fetch_add((gi32 *)(a.row_tickets + (size_t)tour * a.max_tile_rows + blockIdx.y), 1,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old + 1 == (int)gridDim.x - skipped);
+        } else {
+            const int old = __hip_atomic_fetch_sub((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old == 1);
+        }
+    }
+    __syncthreads();
+    if constexpr (HIER) {
+        if (!s_last) return;
+        __syncthreads();   // everyone has read s_last before it is rewritten
+        // last block of this tile row: its first wave folds the row's candidates into one
+        if (tid < 64) {
+            double d = 0.0;
+            u64 k2 = kNoKey;
+            int ev = 0;
+            const size_t row_base = (size_t)tour * a.partial_per_tour + (size_t)blockIdx.y * gridDim.x;
+            for (int bx = skipped + tid; bx < (int)gridDim.x; bx += 64) {
+                double pd; int pi, pj;
+                read_partial(a.partials + row_base + bx, pd, pi, pj);
+                const u64 kk = make_key(pi, pj);
+                if (better(pd, kk, d, k2)) { d = pd; k2 = kk; }
+                if constexpr (TABU)
+                    ev += __hip_atomic_load((gi32 *)(a.slot_evals + row_base + bx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wave_argmin<true>(d, k2);
+            if constexpr (TABU) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) ev += __shfl_xor(ev, off);
+            }
+            if (tid == 0) {
+                const size_t ridx = (size_t)tour * a.max_tile_rows + blockIdx.y;
+                publish_partial(a.row_slots + ridx, d, key_i(k2), key_j(k2));
+                if constexpr (TABU)
+                    __hip_atomic_store((gi32 *)(a.row_evals + ridx), ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (old + 1 == (int)gridDim.y);
+                if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+    if (!s_last) return;
+    TSP_STAMP(5);
+#ifdef TSP_STAMPS
+    apply_step<WT, INT, MODE, RJ, TABU>(a, tour, row_lo, row_hi, stamps);
+#else
+    apply_step<WT, INT, MODE, RJ, TABU>(a, tour, row_lo, row_hi);
+#endif
 }
 
 __global__ void k_stamp_scatter(int *__restrict__ stamp, const int *__restrict__ idx, const int *__restrict__ val,
@@ -441,9 +530,13 @@ using namespace tsp;
 
 namespace {
 
+constexpr int kBestRJ = 2;
+constexpr int kFirstRJ = 1;
+
 template <int MODE>
-dim3 scan_grid(const tsp_dev_tours *t, int RJ) {
+dim3 scan_grid(const tsp_dev_tours *t) {
     const int n = t->n;
+    const int RJ = MODE == TSP_2OPT_BEST ? kBestRJ : kFirstRJ;
     const int gx = (n + kScanThreads * RJ - 1) / (kScanThreads * RJ);
     int gy;
     if (MODE == TSP_2OPT_BEST) gy = (n - 1 + t->best_rows_per_block - 1) / t->best_rows_per_block;
@@ -451,52 +544,82 @@ dim3 scan_grid(const tsp_dev_tours *t, int RJ) {
     return dim3(gx, gy, t->B);
 }
 
-constexpr int kBestRJ = 2;
-constexpr int kFirstRJ = 1;
+StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
+    StepArgs a;
+    a.coord = t->inst->d_coord; a.orders = t->d_order; a.poss = t->d_pos; a.states = t->d_state;
+    a.partials = t->d_partial; a.tickets = t->d_ticket; a.slot_evals = t->d_slot_evals;
+    a.row_tickets = t->d_row_ticket; a.row_slots = t->d_row_slot; a.row_evals = t->d_row_evals;
+    a.max_tile_rows = t->max_tile_rows;
+    a.tabu = tabu ? tabu->d_stamp : nullptr;
+    a.partial_per_tour = t->partial_per_tour;
+    a.n = t->n;
+    a.rows_per_block = mode == TSP_2OPT_BEST ? t->best_rows_per_block : t->first_rows_per_block;
+    a.first_min_rows = std::min(t->first_min_rows, std::max(1, t->n - 1));
+    a.first_max_rows = 0;
+    a.count_evals = t->count_evals;
+    a.iter = iter; a.tenure = tenure;
+    return a;
+}
 
 template <int WT, bool INT>
-int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure, int count_evals) {
+int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
     hipStream_t s = t->inst->ctx->stream;
-    const int n = t->n;
+    StepArgs a = make_args(t, mode, tabu, iter, tenure);
     if (mode == TSP_2OPT_BEST) {
-        const dim3 g = scan_grid<TSP_2OPT_BEST>(t, kBestRJ);
+        const dim3 g = scan_grid<TSP_2OPT_BEST>(t);
         if (tabu)
-            hipLaunchKernelGGL((k_scan<WT, INT, TSP_2OPT_BEST, kBestRJ, true>), g, dim3(kScanThreads), 0, s, t->d_rec,
-                               t->d_state, t->d_partial, n, t->best_rows_per_block, t->partial_per_tour,
-                               tabu->d_stamp, iter, tenure, t->d_slot_evals);
+            hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, true>), g, dim3(kScanThreads), 0, s, a);
         else
-            hipLaunchKernelGGL((k_scan<WT, INT, TSP_2OPT_BEST, kBestRJ, false>), g, dim3(kScanThreads), 0, s,
-                               t->d_rec, t->d_state, t->d_partial, n, t->best_rows_per_block, t->partial_per_tour,
-                               (int *)nullptr, 0, 0, (int *)nullptr);
-        hipLaunchKernelGGL((k_apply<WT, INT, TSP_2OPT_BEST>), dim3(t->B), dim3(kApplyThreads), 0, s, t->d_rec,
-                           t->d_order, t->d_pos, t->d_state, t->d_partial, n, t->best_rows_per_block, (int)g.x,
-                           (int)g.y, t->partial_per_tour, 0, 0, count_evals,
-                           tabu ? (const int *)t->d_slot_evals : (const int *)nullptr);
+            hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, false>), g, dim3(kScanThreads), 0, s, a);
     } else {
-        const dim3 g = scan_grid<TSP_2OPT_FIRST>(t, kFirstRJ);
-        const int rmin = std::min(t->first_rows_per_block * 2, std::max(1, n - 1));
-        const int rmax = (int)g.y * t->first_rows_per_block;
-        hipLaunchKernelGGL((k_scan<WT, INT, TSP_2OPT_FIRST, kFirstRJ, false>), g, dim3(kScanThreads), 0, s, t->d_rec,
-                           t->d_state, t->d_partial, n, t->first_rows_per_block, t->partial_per_tour, (int *)nullptr,
-                           0, 0, (int *)nullptr);
-        hipLaunchKernelGGL((k_apply<WT, INT, TSP_2OPT_FIRST>), dim3(t->B), dim3(kApplyThreads), 0, s, t->d_rec,
-                           t->d_order, t->d_pos, t->d_state, t->d_partial, n, t->first_rows_per_block, (int)g.x,
-                           (int)g.y, t->partial_per_tour, rmin, rmax, count_evals, (const int *)nullptr);
+        const dim3 g = scan_grid<TSP_2OPT_FIRST>(t);
+        a.first_max_rows = (int)g.y * t->first_rows_per_block;
+        hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_FIRST, kFirstRJ, false>), g, dim3(kScanThreads), 0, s, a);
     }
     return TSP_OK;
 }
 
-int launch_step_rt(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure, int count_evals) {
+int launch_step_rt(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
     int rc = TSP_OK;
     TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost,
-                        { rc = launch_step<WTC, INTC>(t, mode, tabu, iter, tenure, count_evals); });
+                        { rc = launch_step<WTC, INTC>(t, mode, tabu, iter, tenure); });
     return rc;
+}
+
+// Tickets for the first step of a run in `mode` (the tours may have been left by a run in the other mode).
+void launch_arm(tsp_dev_tours *t, int mode) {
+    hipStream_t s = t->inst->ctx->stream;
+    if (mode == TSP_2OPT_BEST) {
+        const dim3 g = scan_grid<TSP_2OPT_BEST>(t);
+        hipLaunchKernelGGL((k_arm<TSP_2OPT_BEST>), dim3(t->B), dim3(kScanThreads), 0, s, t->d_state, t->d_ticket,
+                           t->d_row_ticket, t->max_tile_rows, t->n,
+                           t->best_rows_per_block, (int)g.x, (int)g.y, kScanThreads * kBestRJ);
+    } else {
+        const dim3 g = scan_grid<TSP_2OPT_FIRST>(t);
+        hipLaunchKernelGGL((k_arm<TSP_2OPT_FIRST>), dim3(t->B), dim3(kScanThreads), 0, s, t->d_state, t->d_ticket,
+                           t->d_row_ticket, t->max_tile_rows, t->n,
+                           t->first_rows_per_block, (int)g.x, (int)g.y, kScanThreads * kFirstRJ);
+    }
+}
+
+// out[b] (stride in bytes) = recomputed tour cost
+void launch_tour_cost(tsp_dev_tours *t, double *d_out, size_t stride_bytes) {
+    hipStream_t s = t->inst->ctx->stream;
+    TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost, {
+        hipLaunchKernelGGL((k_tour_cost<WTC, INTC>), dim3(t->B), dim3(kApplyThreads), 0, s, t->inst->d_coord,
+                           t->d_order, t->d_pos, t->n, d_out, stride_bytes);
+    });
 }
 
 double wall_s() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
 }
 
 }  // namespace
@@ -511,12 +634,13 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     int64_t queued = 0;
     int status = TSP_OK;
     if (all_done) *all_done = 0;
+    launch_arm(t, mode);
     for (;;) {
         int64_t todo = batch;
         if (max_steps >= 0) todo = std::min<int64_t>(batch, max_steps - queued);
         if (todo <= 0) break;
         for (int64_t k = 0; k < todo; ++k) {
-            int rc = launch_step_rt(t, mode, tabu, iter, tenure, 1);
+            int rc = launch_step_rt(t, mode, tabu, iter, tenure);
             if (rc) return rc;
         }
         queued += todo;
@@ -531,10 +655,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     }
     if (status == TSP_TIME_LIMIT_EXCEEDED && mode == TSP_2OPT_BEST) {
         // the reference recomputes the cost on every exit path (tabusearch.c:168-172)
-        if (t->inst->integer_cost)
-            hipLaunchKernelGGL((k_tour_cost<true>), dim3(t->B), dim3(kApplyThreads), 0, s, t->d_rec, t->d_state, t->n);
-        else
-            hipLaunchKernelGGL((k_tour_cost<false>), dim3(t->B), dim3(kApplyThreads), 0, s, t->d_rec, t->d_state, t->n);
+        launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
         TSP_HIP_TRY(hipStreamSynchronize(s));
     }
     return status;
@@ -547,16 +668,25 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     tsp_dev_tours *t = new tsp_dev_tours();
     t->inst = inst; t->B = B; t->n = inst->n;
+    t->first_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_FIRST_ROWS_PER_BLOCK", 8)));
+    t->first_min_rows = std::max(1, env_int("TSP_FIRST_MIN_ROWS", 32));
+    t->first_max_rows = std::max(t->first_min_rows, env_int("TSP_FIRST_MAX_ROWS", 2048));
+    t->best_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_BEST_ROWS_PER_BLOCK", 32)));
+    t->count_evals = env_int("TSP_COUNT_EVALS", 1);
     const size_t bn = (size_t)B * inst->n;
-    const dim3 gb = scan_grid<TSP_2OPT_BEST>(t, kBestRJ), gf = scan_grid<TSP_2OPT_FIRST>(t, kFirstRJ);
+    const dim3 gb = scan_grid<TSP_2OPT_BEST>(t), gf = scan_grid<TSP_2OPT_FIRST>(t);
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
     TSP_HIP_TRY(hipMalloc(&t->d_order, bn * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_order0, bn * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_pos, bn * sizeof(int)));
-    TSP_HIP_TRY(hipMalloc(&t->d_rec, bn * sizeof(Rec)));
     TSP_HIP_TRY(hipMalloc(&t->d_state, (size_t)B * sizeof(TourState)));
     TSP_HIP_TRY(hipMalloc(&t->d_partial, (size_t)B * t->partial_per_tour * sizeof(Partial)));
     TSP_HIP_TRY(hipMalloc(&t->d_slot_evals, (size_t)B * t->partial_per_tour * sizeof(int)));
+    TSP_HIP_TRY(hipMalloc(&t->d_ticket, (size_t)B * sizeof(int)));
+    t->max_tile_rows = std::max((int)gb.y, (int)gf.y);
+    TSP_HIP_TRY(hipMalloc(&t->d_row_ticket, (size_t)B * t->max_tile_rows * sizeof(int)));
+    TSP_HIP_TRY(hipMalloc(&t->d_row_evals, (size_t)B * t->max_tile_rows * sizeof(int)));
+    TSP_HIP_TRY(hipMalloc(&t->d_row_slot, (size_t)B * t->max_tile_rows * sizeof(Partial)));
     TSP_HIP_TRY(hipHostMalloc(&t->h_state, (size_t)B * sizeof(TourState)));
     *out = t;
     return TSP_OK;
@@ -566,8 +696,9 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     if (!t) return;
     (void)hipSetDevice(t->inst->ctx->device);
     (void)hipStreamSynchronize(t->inst->ctx->stream);
-    (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos); (void)hipFree(t->d_rec);
-    (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals);
+    (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
+    (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket);
+    (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     delete t;
 }
@@ -577,21 +708,16 @@ int tsp_dev_tours_reset(tsp_dev_tours *t) {
     hipStream_t s = t->inst->ctx->stream;
     const int n = t->n, B = t->B;
     TSP_HIP_TRY(hipMemcpyAsync(t->d_order, t->d_order0, (size_t)B * n * sizeof(int), hipMemcpyDeviceToDevice, s));
-    TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost, {
-        hipLaunchKernelGGL((k_build<WTC, INTC>), dim3((n + 255) / 256, B), dim3(256), 0, s, t->inst->d_coord,
-                           t->d_order, t->d_pos, t->d_rec, n);
-    });
+    hipLaunchKernelGGL(k_build_pos, dim3((n + 255) / 256, B), dim3(256), 0, s, t->d_order, t->d_pos, n);
     // control blocks: cursor at sweep start, smallest chunk, obj = uploaded value
-    std::vector<TourState> init((size_t)B);
     for (int b = 0; b < B; ++b) {
         TourState z;
         memset(&z, 0, sizeof z);
-        z.chunk_rows = std::min(t->first_rows_per_block * 2, std::max(1, n - 1));
+        z.chunk_rows = std::min(t->first_min_rows, std::max(1, n - 1));
         z.obj = t->h_obj0[b];
         z.seen_cost = t->h_obj0[b];
-        init[b] = z;
+        t->h_state[b] = z;
     }
-    memcpy(t->h_state, init.data(), sizeof(TourState) * (size_t)B);
     TSP_HIP_TRY(hipMemcpyAsync(t->d_state, t->h_state, sizeof(TourState) * (size_t)B, hipMemcpyHostToDevice, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
@@ -616,10 +742,9 @@ int tsp_dev_tours_upload(tsp_dev_tours *t, const int *succ, int succ_stride, int
         }
         if (v != 0) return TSP_DEV_E_NOT_A_TOUR;
     }
-    std::vector<double> o((size_t)B, 0.0);
-    if (obj) for (int b = 0; b < B; ++b) o[b] = obj[b];
+    t->h_obj0.assign((size_t)B, 0.0);
+    if (obj) for (int b = 0; b < B; ++b) t->h_obj0[b] = obj[b];
     TSP_HIP_TRY(hipMemcpyAsync(t->d_order0, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    t->h_obj0 = o;
     TSP_HIP_TRY(hipStreamSynchronize(s));
     return tsp_dev_tours_reset(t);
 }
@@ -668,14 +793,10 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     TSP_HIP_TRY(hipEventCreate(&e0));
     TSP_HIP_TRY(hipEventCreate(&e1));
     double total = 0.0;
-    const dim3 g = scan_grid<TSP_2OPT_BEST>(t, kBestRJ);
+    launch_arm(t, TSP_2OPT_BEST);
     for (int r = 0; r < reps; ++r) {
         TSP_HIP_TRY(hipEventRecord(e0, s));
-        TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost, {
-            hipLaunchKernelGGL((k_scan<WTC, INTC, TSP_2OPT_BEST, kBestRJ, false>), g, dim3(kScanThreads), 0, s,
-                               t->d_rec, t->d_state, t->d_partial, n, t->best_rows_per_block, t->partial_per_tour,
-                               (int *)nullptr, 0, 0, (int *)nullptr);
-        });
+        launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);
         TSP_HIP_TRY(hipEventRecord(e1, s));
         TSP_HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -690,18 +811,27 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
 
 int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed) {
     if (!t || !packed) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
     hipStream_t s = t->inst->ctx->stream;
-    long long *d_out = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_out, sizeof(long long)));
-    TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost, {
-        hipLaunchKernelGGL((k_best_tour<WTC, INTC>), dim3(1), dim3(kApplyThreads), 0, s, t->d_rec, t->d_state, t->n,
-                           t->B, true_cost, d_out);
-    });
-    long long h = 0;
-    TSP_HIP_TRY(hipMemcpyAsync(&h, d_out, sizeof h, hipMemcpyDeviceToHost, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(d_out);
-    *packed = h;
+    std::vector<double> cost((size_t)t->B);
+    if (true_cost) {
+        double *d_c = nullptr;
+        TSP_HIP_TRY(hipMalloc(&d_c, sizeof(double) * (size_t)t->B));
+        launch_tour_cost(t, d_c, sizeof(double));
+        TSP_HIP_TRY(hipMemcpyAsync(cost.data(), d_c, sizeof(double) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(d_c);
+    } else {
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        for (int b = 0; b < t->B; ++b) cost[b] = t->h_state[b].obj;
+    }
+    int64_t best = INT64_MAX;
+    for (int b = 0; b < t->B; ++b) {
+        const int64_t p = ((int64_t)cost[b] << 24) | (int64_t)b;
+        best = std::min(best, p);
+    }
+    *packed = best;
     return TSP_OK;
 }
 
@@ -797,5 +927,19 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
     if (stats) stats->seconds = wall_s() - t0;
     return status;
 }
+
+#ifdef TSP_STAMPS
+// diagnostic: mean 100 MHz ticks per segment of the last block of a step; resets the sums
+int tsp_dev_debug_stamps(double *out16) {
+    unsigned long long h[16], nn = 0;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tsp::g_stamp_sum), sizeof h) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(&nn, HIP_SYMBOL(tsp::g_stamp_n), sizeof nn) != hipSuccess) return -1;
+    for (int k = 0; k < 16; ++k) out16[k] = nn ? (double)h[k] / (double)nn : 0.0;
+    unsigned long long z[16] = {0}, zn = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_stamp_sum), z, sizeof z);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_stamp_n), &zn, sizeof zn);
+    return (int)nn;
+}
+#endif
 
 }  // extern "C"
