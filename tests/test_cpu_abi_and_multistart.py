@@ -1,0 +1,129 @@
+"""CPU (no GPU): the C-ABI libraries load and export every symbol the headers declare; the
+multi-start sharding / packed all-reduce runs with world_size 2 over gloo; the host logic of the
+binding refuses to run without a device instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsp_dev_\w+|tsp_host_\w+)\s*\(", txt)))
+
+
+def test_libtsp_hip_exports_every_declared_symbol(built):
+    from tsp_optimization_amd import engine as E
+    L = C.CDLL(E.lib_path())
+    names = _declared("include/tsp_hip.h")
+    assert len(names) >= 29
+    assert sorted(names) == sorted(E.EXPORTED)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_libtsp_host_exports_the_reference_entry_points(built):
+    from tsp_optimization_amd.build import lib_path
+    L = C.CDLL(lib_path("libtsp_host.so"))
+    for n in ["calc_dist", "greedy", "grasp", "HEU_greedy", "HEU_Greedy_iter", "HEU_Grasp", "HEU_Grasp_iter",
+              "alg_2opt", "alg_2opt_tabu", "HEU_2opt_grasp", "HEU_2opt_grasp_iter", "HEU_2opt_greedy",
+              "HEU_2opt_greedy_iter", "reverse_path", "copy_instance", "rand_choice", "x_udir_pos",
+              "get_elapsed_time", "free_instance", "TSP_heuc", "parse_comand_line", "parse_instance",
+              "export_tour", "fitness_batch", "HEU_2opt_grasp_multistart", "tsp_host_last_stats",
+              "tsp_host_shutdown"]:
+        assert hasattr(L, n), n
+
+
+def test_no_device_means_error_not_fallback(built):
+    """In this container there is no GPU: opening a context must fail loudly."""
+    from tsp_optimization_amd import engine as E
+    if E.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(E.TspDeviceError):
+        E.Context(0)
+
+
+def test_cli_without_device_exits_with_error(built):
+    from tsp_optimization_amd import engine as E
+    if E.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from tsp_optimization_amd.build import lib_path
+    r = subprocess.run([lib_path("tsp"), "-f", os.path.join(ROOT, "tests/golden/instances/berlin52.tsp"),
+                        "-method", "2OPT_GREEDY", "-seed", "123", "--perfprof", "-verbose", "-1"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "[ERROR]" in r.stderr and r.stdout == ""
+
+
+def test_cli_help_and_methods(built):
+    from tsp_optimization_amd.build import lib_path
+    r = subprocess.run([lib_path("tsp"), "--methods"], capture_output=True, text=True)
+    assert r.returncode == 0 and "2OPT_GREEDY_ITER" in r.stdout
+    r = subprocess.run([lib_path("tsp")], capture_output=True, text=True)
+    assert r.returncode == 1 and "--help" in r.stdout            # src/utility.c:49-52
+    r = subprocess.run([lib_path("tsp"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "-method <type>" in r.stdout
+
+
+def test_pack_orders_by_cost_then_start():
+    from tsp_optimization_amd import multistart as M
+    assert M.unpack(M.pack(28998, 122)) == (28998, 122)
+    assert M.pack(28998, 200) < M.pack(28999, 0)
+    assert M.pack(28998, 5) < M.pack(28998, 6)
+    assert M.local_best([], []) == M.NO_RESULT
+    assert M.shard_starts(10, 1, 4) == [1, 5, 9] and M.owner_of(9, 4) == 1
+
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from tsp_optimization_amd import multistart as M
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+table = json.load(open(os.path.join(sys.argv[1], "tests/golden/oracle_vectors.json")))["att532_multistart256"]
+mine = M.shard_starts(len(table), rank, world)
+# the per-start 2-opt results stand in for what each rank's GPU produced (golden table, oracle-generated)
+packed = M.local_best([table[k]["opt_true"] for k in mine], mine)
+cost, start = M.allreduce_best(packed)
+succ = torch.zeros(8, dtype=torch.int32)
+if M.owner_of(start, world) == rank:
+    succ[:] = torch.tensor([(table[start]["hash"] >> (8 * b)) & 0x7f for b in range(8)], dtype=torch.int32)
+M.broadcast_winner(succ, start, world)
+print(json.dumps({"rank": rank, "n_mine": len(mine), "cost": cost, "start": start, "succ": succ.tolist()}))
+dist.destroy_process_group()
+'''
+
+
+def test_multistart_allreduce_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=240)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
+    exp = golden("survey_appendix_b.json")["att532"]["multistart256"]
+    table = golden("oracle_vectors.json")["att532_multistart256"]
+    want = [(table[exp["best_start"]]["hash"] >> (8 * b)) & 0x7f for b in range(8)]
+    for o in outs:
+        assert (o["cost"], o["start"]) == (exp["best_true"], exp["best_start"])   # 28998 at start 122
+        assert o["n_mine"] == 128 and o["succ"] == want

@@ -1,0 +1,564 @@
+/*
+ * tsp_host.c -- the reference's heuristics entry points as thin C shims over libtsp_hip.so.
+ *
+ * Every function that the reference implements as an O(n^2) or O(n^2)-per-move CPU loop
+ * (greedy, grasp, their multistart wrappers, alg_2opt, alg_2opt_tabu, fitness) marshals the
+ * instance's own arrays into one call of the C ABI (include/tsp_hip.h) and writes the result back
+ * in place, keeping the reference's data contract: edges[k].i == k, edges[k].j == succ(k),
+ * obj_best updated as the reference updates it.  No distance, scan or reversal is computed here.
+ */
+#define _DEFAULT_SOURCE
+#include "tsp_host.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include "../../include/tsp_hip.h"
+
+#define GRASP_ITER_TIME_LIM 120 /* src/heuristics.c:11 */
+#define MULTISTART_BATCH 256    /* GRASP starts constructed per device call in HEU_Grasp_iter */
+
+/* ---- device context and instance cache -------------------------------------------------------- */
+
+typedef struct {
+    const point *nodes; /* identity of the host array the upload was made from */
+    int n, wtype, integer_cost;
+    double checksum;    /* guards against a reused pointer with different content */
+    tsp_dev_inst *dev;
+    unsigned long stamp;
+} cache_slot;
+
+#define CACHE_SLOTS 8
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static tsp_dev_ctx *g_ctx = NULL;
+static cache_slot g_cache[CACHE_SLOTS];
+static unsigned long g_clock = 0;
+static __thread long long t_sweeps, t_evals, t_moves;
+static __thread double t_device_ms;
+
+static void dev_fail(const char *what, int rc) {
+    LOG_E("%s failed with %d %s (this build has no CPU path: an MI355X and libtsp_hip.so are required)", what, rc,
+          tsp_dev_last_error());
+}
+
+static tsp_dev_ctx *ctx_locked(void) {
+    if (!g_ctx) {
+        const char *d = getenv("TSP_DEVICE");
+        int rc = tsp_dev_open(d ? atoi(d) : 0, &g_ctx);
+        if (rc) dev_fail("tsp_dev_open", rc);
+        atexit(tsp_host_shutdown);
+    }
+    return g_ctx;
+}
+
+static double nodes_checksum(const point *p, int n) {
+    double s = 0.0;
+    for (int k = 0; k < n; k++) s += p[k].x * 1.000001 + p[k].y;
+    return s;
+}
+
+/* Device copy of inst->nodes (uploaded on first use, then reused while the host array is unchanged). */
+static tsp_dev_inst *dev_inst_locked(instance *inst) {
+    if (!inst->nodes || inst->num_nodes < 4) LOG_E("instance has no nodes (or fewer than 4)");
+    const double sum = nodes_checksum(inst->nodes, inst->num_nodes);
+    const int ic = inst->params.integer_cost ? 1 : 0;
+    int victim = 0;
+    for (int k = 0; k < CACHE_SLOTS; k++) {
+        cache_slot *c = &g_cache[k];
+        if (c->dev && c->nodes == inst->nodes && c->n == inst->num_nodes && c->wtype == (int)inst->weight_type &&
+            c->integer_cost == ic && c->checksum == sum) {
+            c->stamp = ++g_clock;
+            return c->dev;
+        }
+        if (g_cache[k].stamp < g_cache[victim].stamp) victim = k;
+    }
+    cache_slot *c = &g_cache[victim];
+    if (c->dev) tsp_dev_inst_destroy(c->dev);
+    memset(c, 0, sizeof *c);
+    int rc = tsp_dev_inst_create(ctx_locked(), (const double *)inst->nodes, inst->num_nodes, (int)inst->weight_type, ic,
+                                 &c->dev);
+    if (rc) dev_fail("tsp_dev_inst_create", rc);
+    c->nodes = inst->nodes; c->n = inst->num_nodes; c->wtype = (int)inst->weight_type; c->integer_cost = ic;
+    c->checksum = sum; c->stamp = ++g_clock;
+    return c->dev;
+}
+
+void tsp_host_shutdown(void) {
+    pthread_mutex_lock(&g_lock);
+    for (int k = 0; k < CACHE_SLOTS; k++)
+        if (g_cache[k].dev) { tsp_dev_inst_destroy(g_cache[k].dev); memset(&g_cache[k], 0, sizeof g_cache[k]); }
+    if (g_ctx) { tsp_dev_close(g_ctx); g_ctx = NULL; }
+    pthread_mutex_unlock(&g_lock);
+}
+
+void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms) {
+    if (sweeps) *sweeps = t_sweeps;
+    if (evals) *evals = t_evals;
+    if (moves) *moves = t_moves;
+    if (device_ms) *device_ms = t_device_ms;
+}
+
+static void keep_stats(const tsp_two_opt_stats *st) {
+    t_sweeps = st->sweeps; t_evals = st->evals; t_moves = st->moves; t_device_ms = st->device_ms;
+}
+
+static double limit_of(const instance *inst) { return inst->params.time_limit > 0 ? (double)inst->params.time_limit : -1.0; }
+
+/* ---- src/distutil.c:73 -------------------------------------------------------------------------- */
+double calc_dist(int i, int j, instance *inst) {
+    double d = 0.0;
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_dist_pairs(dev_inst_locked(inst), &i, &j, 1, &d);
+    pthread_mutex_unlock(&g_lock);
+    if (rc) dev_fail("tsp_dev_dist_pairs", rc);
+    return d;
+}
+
+/* ---- small host helpers (src/utility.c) ------------------------------------------------------------ */
+int x_udir_pos(int i, int j, int num_nodes) { /* :17-30 */
+    if (i == j) LOG_E("Indexes passed are equal!");
+    if (i > num_nodes - 1 || j > num_nodes - 1) LOG_E("Indexes passed greater than the number of nodes");
+    if (i > j) { int t = i; i = j; j = t; }
+    return i * num_nodes + j - ((i + 1) * (i + 2)) / 2;
+}
+
+double get_elapsed_time(struct timeval start, struct timeval end) { /* :701-706 */
+    return (double)(end.tv_sec - start.tv_sec) + 1e-6 * (double)(end.tv_usec - start.tv_usec);
+}
+
+/* :708-722.  Host-side list surgery for callers that kick a tour themselves (tabu, VNS drivers). */
+void reverse_path(instance *inst, int start_node, int end_node, int *prev) {
+    edge *e = inst->solution.edges;
+    for (int cur = start_node;;) {
+        const int p = prev[cur];
+        e[cur].j = p;
+        cur = p;
+        if (p == end_node) break;
+    }
+    for (int k = 0; k < inst->num_nodes; k++) prev[e[k].j] = k;
+}
+
+void copy_instance(instance *dst, instance *src) { /* :724-743 */
+    *dst = *src;
+    dst->name = NULL; dst->comment = NULL; dst->params.file_path = NULL; dst->params.method.name = NULL;
+    dst->thread_seeds = NULL;
+    if (src->nodes) {
+        dst->nodes = malloc(sizeof(point) * (size_t)src->num_nodes);
+        memcpy(dst->nodes, src->nodes, sizeof(point) * (size_t)src->num_nodes);
+    }
+    if (src->ind) {
+        dst->ind = malloc(sizeof(int) * (size_t)src->num_columns);
+        memcpy(dst->ind, src->ind, sizeof(int) * (size_t)src->num_columns);
+    }
+    if (src->solution.edges) {
+        dst->solution.edges = malloc(sizeof(edge) * (size_t)src->num_nodes);
+        memcpy(dst->solution.edges, src->solution.edges, sizeof(edge) * (size_t)src->num_nodes);
+    }
+}
+
+int rand_choice(int from, int to) { return from + (int)(URAND() * (to - from)); } /* :752-753 */
+
+void free_instance(instance *inst) { /* :340-349 */
+    free(inst->params.file_path); inst->params.file_path = NULL;
+    free(inst->name); inst->name = NULL;
+    free(inst->comment); inst->comment = NULL;
+    free(inst->nodes); inst->nodes = NULL;
+    free(inst->ind); inst->ind = NULL;
+    free(inst->thread_seeds); inst->thread_seeds = NULL;
+    free(inst->solution.edges); inst->solution.edges = NULL;
+    free(inst->solution.xbest); inst->solution.xbest = NULL;
+}
+
+/* ---- constructive heuristics ------------------------------------------------------------------------- */
+
+static void stamp_edge_sources(instance *inst) {
+    for (int k = 0; k < inst->num_nodes; k++) inst->solution.edges[k].i = k;
+}
+
+static int construct_one(instance *inst, int kind, int start, const double *urand) {
+    if (start >= inst->num_nodes) return WRONG_STARTING_NODE; /* heuristics.c:20 / :84 */
+    double obj = 0.0;
+    int status = 0;
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_construct(dev_inst_locked(inst), kind, 1, &start, urand, &inst->solution.edges[0].j, 2,
+                               2 * (int64_t)inst->num_nodes, &obj, &status);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_construct", rc);
+    if (status) return status;
+    stamp_edge_sources(inst);
+    inst->solution.obj_best = obj;
+    return 0;
+}
+
+int greedy(instance *inst, int starting_node) { return construct_one(inst, TSP_CONSTRUCT_GREEDY, starting_node, NULL); }
+
+int grasp(instance *inst, int starting_node) {
+    if (starting_node >= inst->num_nodes) return WRONG_STARTING_NODE;
+    /* the reference draws one URAND() per loop iteration, n per call (heuristics.c:127) */
+    double *u = malloc(sizeof(double) * (size_t)inst->num_nodes);
+    for (int k = 0; k < inst->num_nodes; k++) u[k] = URAND();
+    int st = construct_one(inst, TSP_CONSTRUCT_GRASP, starting_node, u);
+    free(u);
+    return st;
+}
+
+int HEU_greedy(instance *inst) { return greedy(inst, 0); } /* :160 */
+int HEU_Grasp(instance *inst) { return grasp(inst, 0); }   /* :505 */
+
+/* :168-205 -- all n starting nodes in one batched device call; the first strictly better start wins */
+int HEU_Greedy_iter(instance *inst) {
+    const int n = inst->num_nodes;
+    int *starts = malloc(sizeof(int) * (size_t)n);
+    int *succ = malloc(sizeof(int) * (size_t)n * n);
+    double *obj = malloc(sizeof(double) * (size_t)n);
+    for (int k = 0; k < n; k++) starts[k] = k;
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_construct(dev_inst_locked(inst), TSP_CONSTRUCT_GREEDY, n, starts, NULL, succ, 1, n, obj, NULL);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_construct", rc);
+    int best = 0;
+    for (int k = 1; k < n; k++) if (obj[k] < obj[best]) best = k;
+    for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = succ[(size_t)best * n + v]; }
+    inst->solution.obj_best = obj[best];
+    free(starts); free(succ); free(obj);
+    return 0;
+}
+
+/* :510-544 -- wall-clock bounded random restarts.  The RNG stream is consumed in the reference's
+ * order (start node :519, then the n draws of grasp()); starts are built MULTISTART_BATCH at a time. */
+int HEU_Grasp_iter(instance *inst, int time_lim) {
+    const int n = inst->num_nodes;
+    const int limit = time_lim > 0 ? time_lim : GRASP_ITER_TIME_LIM;
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    const int B = MULTISTART_BATCH;
+    int *starts = malloc(sizeof(int) * B);
+    double *u = malloc(sizeof(double) * (size_t)B * n);
+    int *succ = malloc(sizeof(int) * (size_t)B * n);
+    double *obj = malloc(sizeof(double) * B);
+    double best = DBL_MAX;
+    edge *best_edges = calloc((size_t)n, sizeof(edge));
+    for (;;) {
+        for (int b = 0; b < B; b++) {
+            starts[b] = (int)(URAND() * (n - 1));
+            for (int k = 0; k < n; k++) u[(size_t)b * n + k] = URAND();
+        }
+        gettimeofday(&t1, 0);
+        if (get_elapsed_time(t0, t1) >= limit) break;
+        pthread_mutex_lock(&g_lock);
+        int rc = tsp_dev_construct(dev_inst_locked(inst), TSP_CONSTRUCT_GRASP, B, starts, u, succ, 1, n, obj, NULL);
+        pthread_mutex_unlock(&g_lock);
+        if (rc < 0) dev_fail("tsp_dev_construct", rc);
+        for (int b = 0; b < B; b++)
+            if (obj[b] < best) {
+                best = obj[b];
+                for (int v = 0; v < n; v++) { best_edges[v].i = v; best_edges[v].j = succ[(size_t)b * n + v]; }
+            }
+    }
+    inst->solution.obj_best = best;
+    memcpy(inst->solution.edges, best_edges, sizeof(edge) * (size_t)n);
+    free(starts); free(u); free(succ); free(obj); free(best_edges);
+    return TIME_LIMIT_EXCEEDED; /* the reference only ever leaves this loop through the time limit (:522-524) */
+}
+
+/* ---- refinement ------------------------------------------------------------------------------------------ */
+
+/* src/heuristics.c:438-502 */
+int alg_2opt(instance *inst) {
+    tsp_two_opt_stats st;
+    memset(&st, 0, sizeof st);
+    double obj = inst->solution.obj_best;
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_two_opt(dev_inst_locked(inst), TSP_2OPT_FIRST, TSP_ENGINE_AUTO, 1, &inst->solution.edges[0].j, 2,
+                             2 * (int64_t)inst->num_nodes, &obj, limit_of(inst), &st);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_two_opt", rc);
+    inst->solution.obj_best = obj;
+    keep_stats(&st);
+    if (rc == TIME_LIMIT_EXCEEDED) LOG_I("2-opt heuristics time exceeded");
+    return rc;
+}
+
+/* src/tabusearch.c:107-178.  skip_edge is the caller's host array of n(n-1)/2 stamps, so it is
+ * moved to the device and back around the call (callers that keep the stamps resident use
+ * tsp_dev_two_opt_tabu directly). */
+int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int iter, const int tenure) {
+    tsp_two_opt_stats st;
+    memset(&st, 0, sizeof st);
+    double obj = inst->solution.obj_best;
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_inst *d = dev_inst_locked(inst);
+    tsp_dev_tabu *tb = NULL;
+    int rc = 0;
+    if (skip_edge) {
+        rc = tsp_dev_tabu_create(d, &tb);
+        if (!rc) rc = tsp_dev_tabu_upload(tb, skip_edge);
+    }
+    if (!rc) rc = tsp_dev_two_opt_tabu(d, tb, iter, tenure, &inst->solution.edges[0].j, 2, &obj, stored_prev,
+                                       limit_of(inst), &st);
+    if (tb) {
+        if (rc >= 0) { int rc2 = tsp_dev_tabu_download(tb, skip_edge); if (rc2) rc = rc2; }
+        tsp_dev_tabu_destroy(tb);
+    }
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_two_opt_tabu", rc);
+    inst->solution.obj_best = obj;
+    keep_stats(&st);
+    if (rc == TIME_LIMIT_EXCEEDED) LOG_I("2-opt heuristics time exceeded");
+    return rc;
+}
+
+/* src/heuristics.c:547-594: the constructive status is overwritten by the 2-opt status, as there */
+int HEU_2opt_grasp(instance *inst) { (void)HEU_Grasp(inst); return alg_2opt(inst); }
+int HEU_2opt_grasp_iter(instance *inst) { (void)HEU_Grasp_iter(inst, inst->params.time_limit / 5); return alg_2opt(inst); }
+int HEU_2opt_greedy(instance *inst) { (void)HEU_greedy(inst); return alg_2opt(inst); }
+int HEU_2opt_greedy_iter(instance *inst) { (void)HEU_Greedy_iter(inst); return alg_2opt(inst); }
+
+/* genetic.c:51-60 for `count` chromosomes of n nodes each */
+int fitness_batch(instance *inst, const int *chromosomes, int count, double *fitness_out) {
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_perm_cost(dev_inst_locked(inst), count, chromosomes, inst->num_nodes, fitness_out);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_perm_cost", rc);
+    return rc;
+}
+
+/* BASELINE config 4: S GRASP starts (stream order of heuristics.c:519,:127), alg_2opt on each, best true cost */
+int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+    const int n = inst->num_nodes;
+    if (starts < 1 || world < 1 || rank < 0 || rank >= world) return -1;
+    int mine = 0;
+    for (int k = 0; k < starts; k++) mine += (k % world == rank);
+    int *node = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
+    int *gid = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
+    double *u = malloc(sizeof(double) * (size_t)(mine ? mine : 1) * n);
+    int m = 0;
+    for (int k = 0; k < starts; k++) { /* every rank walks the whole stream so that start k is the same everywhere */
+        const int nd = (int)(URAND() * (n - 1));
+        if (k % world == rank) {
+            node[m] = nd; gid[m] = k;
+            for (int q = 0; q < n; q++) u[(size_t)m * n + q] = URAND();
+            m++;
+        } else {
+            for (int q = 0; q < n; q++) (void)random();
+        }
+    }
+    int *succ = malloc(sizeof(int) * (size_t)(mine ? mine : 1) * n);
+    double *obj = malloc(sizeof(double) * (size_t)(mine ? mine : 1));
+    double *truec = malloc(sizeof(double) * (size_t)(mine ? mine : 1));
+    double best = DBL_MAX;
+    int best_k = -1, best_m = -1;
+    if (mine > 0) {
+        pthread_mutex_lock(&g_lock);
+        tsp_dev_inst *d = dev_inst_locked(inst);
+        int rc = tsp_dev_construct(d, TSP_CONSTRUCT_GRASP, mine, node, u, succ, 1, n, obj, NULL);
+        if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, obj, limit_of(inst), NULL);
+        if (rc >= 0) {  /* true cost = fitness of the tour walked from node 0 (the reported obj carries GRASP's offset) */
+            int *perm = malloc(sizeof(int) * (size_t)mine * n);
+            for (int b = 0; b < mine; b++) { int v = 0; for (int q = 0; q < n; q++) { perm[(size_t)b * n + q] = v; v = succ[(size_t)b * n + v]; } }
+            int rc2 = tsp_dev_perm_cost(d, mine, perm, n, truec);
+            if (rc2) rc = rc2;
+            free(perm);
+        }
+        pthread_mutex_unlock(&g_lock);
+        if (rc < 0) dev_fail("multistart", rc);
+        for (int b = 0; b < mine; b++)
+            if (truec[b] < best) { best = truec[b]; best_k = gid[b]; best_m = b; }
+        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = succ[(size_t)best_m * n + v]; }
+        inst->solution.obj_best = best;
+    }
+    if (best_true_cost) *best_true_cost = best;
+    if (best_start) *best_start = best_k;
+    free(node); free(gid); free(u); free(succ); free(obj); free(truec);
+    return 0;
+}
+
+/* ---- src/solver.c:262-299 ------------------------------------------------------------------------------- */
+int TSP_heuc(instance *inst) {
+    if (inst->params.seed >= 0) srandom((unsigned)inst->params.seed);
+    inst->num_columns = (long)inst->num_nodes * (inst->num_nodes - 1) / 2;
+    inst->solution.edges = calloc((size_t)inst->num_nodes, sizeof(edge));
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    switch (inst->params.method.id) { /* solver.c:114-151, heuristics of this round */
+    case SOLVE_GREEDY: HEU_greedy(inst); break;
+    case SOLVE_GREEDY_ITER: HEU_Greedy_iter(inst); break;
+    case SOLVE_GRASP: HEU_Grasp(inst); break;
+    case SOLVE_GRASP_ITER: HEU_Grasp_iter(inst, inst->params.time_limit); break;
+    case SOLVE_2OPT_GRASP: HEU_2opt_grasp(inst); break;
+    case SOLVE_2OPT_GRASP_ITER: HEU_2opt_grasp_iter(inst); break;
+    case SOLVE_2OPT_GREEDY: HEU_2opt_greedy(inst); break;
+    case SOLVE_2OPT_GREEDY_ITER: HEU_2opt_greedy_iter(inst); break;
+    default:
+        LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, GRASP, GRASP_ITER, "
+              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER)",
+              inst->params.method.name ? inst->params.method.name : "?");
+    }
+    gettimeofday(&t1, 0);
+    const double elapsed = get_elapsed_time(t0, t1);
+    inst->solution.time_to_solve = elapsed;
+    export_tour(inst);
+    if (inst->params.perf_prof) printf("%0.2f", inst->solution.obj_best);          /* solver.c:291-292 */
+    else printf("\n\n\nTIME TO SOLVE %0.6fs\n\n\n", elapsed);                       /* solver.c:295 */
+    return 0;
+}
+
+/* ---- CLI edge ---------------------------------------------------------------------------------------------- */
+
+/* The reference matches -method by a cascade of strncmp prefixes in which later matches override
+ * earlier ones (src/utility.c:100-277); the table keeps that order and those lengths. */
+static const struct { const char *prefix; int len; solver_type id; const char *name; } k_methods[] = {
+    {"GREEDY", 6, SOLVE_GREEDY, "GREEDY HEURISTIC"},
+    {"GREEDY_ITER", 11, SOLVE_GREEDY_ITER, "GREEDY ITERATIVE HEURISTIC"},
+    {"EXTR_MIL", 6, SOLVE_EXTR_MIL, "EXTRA MILEAGE HEURISTIC"},
+    {"GRASP", 5, SOLVE_GRASP, "GRASP HEURISTIC"},
+    {"GRASP_ITER", 10, SOLVE_GRASP_ITER, "GRASP ITERATIVE HEURISTIC"},
+    {"2OPT_GRASP", 9, SOLVE_2OPT_GRASP, "2-OPT HEURISTIC WITH GRASP INITIALIZATION"},
+    {"2OPT_GRASP_ITER", 15, SOLVE_2OPT_GRASP_ITER, "2-OPT HEURISTIC WITH ITERATIVE GRASP INITIALIZATION"},
+    {"2OPT_GREEDY", 11, SOLVE_2OPT_GREEDY, "2-OPT HEURISTIC WITH GREEDY INITIALIZATION"},
+    {"2OPT_GREEDY_ITER", 16, SOLVE_2OPT_GREEDY_ITER, "2-OPT HEURISTIC WITH ITERATIVE GREEDY INITIALIZATION"},
+    {"2OPT_EXTR_MIL", 13, SOLVE_2OPT_EXTR_MIL, "2-OPT HEURISTIC WITH EXTRA MILEAGE INITIALIZATION"},
+    {"VNS", 3, SOLVE_VNS, "VNS META-HEURISTIC"},
+    {"TABU_STEP", 9, SOLVE_TABU_STEP, "TABU SEARCH META-HEURISTIC WITH STEP POLICY"},
+    {"TABU_LIN", 8, SOLVE_TABU_LIN, "TABU SEARCH META-HEURISTIC WITH LINEAR POLICY"},
+    {"TABU_RAND", 9, SOLVE_TABU_RAND, "TABU SEARCH META-HEURISTIC WITH RANDOM POLICY"},
+    {"GENETIC", 7, SOLVE_GENETIC, "GENETIC ALGORITHM META-HEURISTIC"},
+};
+
+static char *dup_string(const char *s) {
+    char *d = malloc(strlen(s) + 1);
+    strcpy(d, s);
+    return d;
+}
+
+void parse_comand_line(int argc, const char *argv[], instance *inst) { /* src/utility.c:47-338 */
+    if (argc <= 1) { printf("Type \"%s --help\" to see available comands\n", argv[0]); exit(1); }
+    memset(inst, 0, sizeof *inst);
+    inst->params.method.id = SOLVE_2OPT_GREEDY; /* the reference's default is a CPLEX method (:54); not buildable here */
+    inst->params.method.edge_type = UDIR_EDGE;
+    inst->params.method.name = (char *)"2-OPT HEURISTIC WITH GREEDY INITIALIZATION";
+    inst->params.time_limit = -1;
+    inst->params.num_threads = -1;
+    inst->params.verbose = 1;
+    inst->params.integer_cost = 1;
+    inst->params.seed = (int)time(NULL);
+    int need_help = 0, show_methods = 0;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        const int has_value = i < argc - 1;
+        if (!strcmp(a, "-f")) { if (!has_value) { need_help = 1; continue; } inst->params.file_path = dup_string(argv[++i]); continue; }
+        if (!strcmp(a, "-t")) { if (!has_value) { need_help = 1; continue; } inst->params.time_limit = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "-threads")) { if (!has_value) { need_help = 1; continue; } inst->params.num_threads = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "-verbose")) { if (!has_value) { need_help = 1; continue; } inst->params.verbose = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "-seed")) { if (!has_value) { need_help = 1; continue; } inst->params.seed = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "-method")) {
+            if (!has_value) { need_help = 1; continue; }
+            const char *m = argv[++i];
+            int hit = 0;
+            for (size_t k = 0; k < sizeof k_methods / sizeof k_methods[0]; k++)
+                if (!strncmp(m, k_methods[k].prefix, (size_t)k_methods[k].len)) {
+                    inst->params.method.id = k_methods[k].id;
+                    inst->params.method.name = (char *)k_methods[k].name;
+                    inst->params.method.use_cplex = 0;
+                    hit = 1;
+                }
+            if (!hit) LOG_E("method %s needs CPLEX, which this build does not link (heuristics path only)", m);
+            continue;
+        }
+        if (!strcmp(a, "--fcost")) { inst->params.integer_cost = 0; continue; }
+        if (!strcmp(a, "--methods")) { show_methods = 1; continue; }
+        if (!strcmp(a, "--perfprof")) { inst->params.perf_prof = 1; continue; }
+        if (!strcmp(a, "--v") || !strcmp(a, "--version")) { printf("Version %s\n", "mi355x-r1"); exit(0); }
+        need_help = 1;
+    }
+    if (show_methods) {
+        for (size_t k = 0; k < sizeof k_methods / sizeof k_methods[0]; k++) printf("%-18s %s\n", k_methods[k].prefix, k_methods[k].name);
+        exit(0);
+    }
+    if (need_help) {
+        printf("-f <file's path>          To pass the problem's path\n");
+        printf("-t <time>                 The time limit in seconds\n");
+        printf("-threads <num threads>    The number of threads to use\n");
+        printf("-verbose <level>          The verbosity level of the debugging printing\n");
+        printf("-method <type>            The method used to solve the problem. Use \"--methods\" to see the list of available methods\n");
+        printf("-seed <seed>              The seed for random generation\n");
+        printf("--fcost                   Whether you want float costs in the problem\n");
+        printf("--perfprof                Print only the objective (machine mode)\n");
+        printf("--v, --version            Software's current version\n");
+        exit(0);
+    }
+}
+
+void parse_instance(instance *inst) { /* src/utility.c:351-453: TSPLIB NODE_COORD_SECTION files */
+    if (!inst->params.file_path) LOG_E("You didn't pass any file!");
+    FILE *fp = fopen(inst->params.file_path, "r");
+    if (!fp) LOG_E("Unable to open file!");
+    inst->num_nodes = -1;
+    inst->weight_type = (weight_type)-1;
+    inst->num_columns = -1;
+    char line[256];
+    const char *sep = " :\n\t\r";
+    int in_coords = 0;
+    while (fgets(line, sizeof line, fp)) {
+        char *key = strtok(line, sep);
+        if (!key) continue;
+        if (!strncmp(key, "EOF", 3)) break;
+        if (!strncmp(key, "NAME", 4)) { char *v = strtok(NULL, sep); if (v) { free(inst->name); inst->name = dup_string(v); } in_coords = 0; continue; }
+        if (!strncmp(key, "COMMENT", 7)) { in_coords = 0; continue; }
+        if (!strncmp(key, "TYPE", 4)) {
+            char *v = strtok(NULL, sep);
+            if (!v || strncmp(v, "TSP", 3)) LOG_E(" format error:  only TYPE == TSP implemented so far!");
+            in_coords = 0; continue;
+        }
+        if (!strncmp(key, "DIMENSION", 9)) {
+            char *v = strtok(NULL, sep);
+            inst->num_nodes = v ? atoi(v) : -1;
+            if (inst->num_nodes > 0) inst->nodes = calloc((size_t)inst->num_nodes, sizeof(point));
+            in_coords = 0; continue;
+        }
+        if (!strncmp(key, "EDGE_WEIGHT_TYPE", 16)) {
+            char *v = strtok(NULL, sep);
+            if (v) {
+                if (!strncmp(v, "EUC_2D", 6)) inst->weight_type = EUC_2D;
+                if (!strncmp(v, "MAX_2D", 6)) inst->weight_type = MAX_2D;
+                if (!strncmp(v, "MAN_2D", 6)) inst->weight_type = MAN_2D;
+                if (!strncmp(v, "CEIL_2D", 7)) inst->weight_type = CEIL_2D;
+                if (!strncmp(v, "GEO", 3)) inst->weight_type = GEO;
+                if (!strncmp(v, "ATT", 3)) inst->weight_type = ATT;
+                if (!strncmp(v, "EXPLICIT", 8)) LOG_E("Wrong edge weight type, this program resolve only 2D TSP case with coordinate type.");
+            }
+            in_coords = 0; continue;
+        }
+        if (!strncmp(key, "NODE_COORD_SECTION", 18)) { in_coords = 1; continue; }
+        if (!strncmp(key, "EDGE_WEIGHT_SECTION", 19)) { in_coords = 0; continue; }
+        if (in_coords) {
+            const int id = atoi(key) - 1;
+            if (!inst->nodes || id < 0 || id >= inst->num_nodes) LOG_E(" ... unknown node in NODE_COORD_SECTION section");
+            char *a = strtok(NULL, sep), *b = strtok(NULL, sep);
+            if (!a || !b) LOG_E(" ... malformed coordinate line");
+            inst->nodes[id].x = atof(a);
+            inst->nodes[id].y = atof(b);
+        }
+    }
+    fclose(fp);
+    if (inst->num_nodes <= 0 || !inst->nodes) LOG_E("no DIMENSION in %s", inst->params.file_path);
+    if (!inst->name) inst->name = dup_string("unnamed");
+}
+
+void export_tour(instance *inst) { /* src/utility.c:523-555: TSPLIB TOUR + OBJECTIVE/TIME lines */
+    if (inst->params.perf_prof) return;
+    mkdir("../tour", 0777);
+    char path[1024];
+    snprintf(path, sizeof path, "../tour/%s.tour", inst->name);
+    FILE *f = fopen(path, "w");
+    if (!f) { printf("Unable to save the tour file\n"); return; }
+    fprintf(f, "NAME : %s.tour\nTYPE : TOUR\nDIMENSION : %d\nOBJECTIVE : %f\nTIME : %f\nTOUR_SECTION\n", inst->name,
+            inst->num_nodes, inst->solution.obj_best, inst->solution.time_to_solve);
+    int v = 0;
+    for (int k = 0; k < inst->num_nodes; k++) { fprintf(f, "%d\n", v + 1); v = inst->solution.edges[v].j; }
+    fprintf(f, "-1\nEOF");
+    fclose(f);
+}
