@@ -114,6 +114,10 @@ int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count
  * integer costs), else double.  *kernel_ms receives the kernel's device time if not NULL. */
 int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float *kernel_ms);
 
+/* Self-test: out[k] = the hardware's approximate v_sqrt_f64(in[k]).  The exact integer-root
+ * variants used for integer coordinates rely on its error bound; tests measure it through this. */
+int tsp_dev_selftest_raw_sqrt(tsp_dev_ctx *ctx, const double *in, int count, double *out);
+
 /* ---- construction: greedy() / grasp() for B starting nodes at once ------------------------ */
 /* kind = TSP_CONSTRUCT_*.  starts[B].  urand: B x n doubles in [0,1], the values URAND()
  * (include/utility.h:36) would return for start b, in draw order (grasp draws exactly n per

@@ -290,3 +290,87 @@ def test_perm_cost_matches_fitness(eng, ctx, integer_cost):
     inst.close()
     exp = np.array([O.perm_cost(xy, wt, p, integer_cost) for p in perms])
     assert (got == exp).all()
+
+
+# ---- exact integer roots (the *_ICOORD kernel variants used for integer coordinates) ------------
+def _boundary_pairs(rng, targets_fn, ks):
+    """Integer (dx, dy) whose squared length sits on / next to a rounding boundary of the metric."""
+    out = []
+    for k in ks:
+        for s in targets_fn(int(k)):
+            if s < 0:
+                continue
+            for dy in range(0, 4000):
+                r2 = s - dy * dy
+                if r2 < 0:
+                    break
+                dx = int(np.sqrt(float(r2)))
+                for c in (dx - 1, dx, dx + 1):
+                    if c >= 0 and c * c == r2:
+                        out.append((c, dy))
+                        break
+                else:
+                    continue
+                break
+    return out
+
+
+@pytest.mark.parametrize("wt,targets", [
+    (O.EUC_2D, lambda k: [k * k + k, k * k + k + 1, k * k - k, k * k - k + 1, k * k]),
+    (O.CEIL_2D, lambda k: [k * k, k * k + 1, k * k - 1]),
+    (O.ATT, lambda k: [10 * k * k, 10 * k * k + 1, 10 * k * k - 1]),
+])
+def test_integer_root_boundaries_bit_exact(eng, ctx, wt, targets):
+    rng = np.random.default_rng(8)
+    ks = np.concatenate([np.arange(0, 60), rng.integers(60, 5000, 150), rng.integers(5000, 1_400_000, 400),
+                         rng.integers(1_400_000, 2_000_000, 100)])
+    if wt == O.ATT:
+        ks = ks // 3
+    pairs = _boundary_pairs(rng, targets, ks)
+    assert len(pairs) > 300
+    xy = np.array([[0, 0]] + [[dx, dy] for dx, dy in pairs], dtype=np.float64)
+    xy = np.minimum(xy, 1_450_000.0)                  # keep the span inside the integer-variant bound
+    inst = eng.Instance(ctx, xy, wt, 1)
+    i = np.zeros(len(xy) - 1, dtype=np.int32)
+    j = np.arange(1, len(xy), dtype=np.int32)
+    got = inst.dist_pairs(i, j)
+    # and random pairs among the boundary points
+    i2 = rng.integers(0, len(xy), 20000).astype(np.int32)
+    j2 = rng.integers(0, len(xy), 20000).astype(np.int32)
+    got2 = inst.dist_pairs(i2, j2)
+    inst.close()
+    exp = np.array([O.dist(xy, 0, int(b), wt) for b in j])
+    exp2 = np.array([O.dist(xy, int(a), int(b), wt) for a, b in zip(i2, j2)])
+    assert (got == exp).all() and (got2 == exp2).all()
+
+
+def test_integer_variant_equals_general_variant_on_a_descent(eng, ctx, monkeypatch):
+    """Same instance through the general fp64 path (TSP_NO_ICOORD=1) and the integer-root path."""
+    xy = rand_instance(1500, seed=77)
+    _, succ0, obj0 = O.greedy(xy, O.EUC_2D)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TSP_NO_ICOORD", flag)
+        inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+        res.append(inst.two_opt(succ0, obj0, mode=eng.BEST))
+        inst.close()
+    assert (res[0][1] == res[1][1]).all() and res[0][2] == res[1][2]
+    assert res[0][3]["sweeps"] == res[1][3]["sweeps"]
+
+
+def test_raw_sqrt_error_budget_of_the_integer_variants(eng, ctx):
+    """int_root() needs |v_sqrt_f64(s) - sqrt(s)| < 0.25 for roots below 2^21, i.e. a relative error
+    below 2^-23 (the ISA manual's bound).  Measure it: random and boundary integers up to 2^42."""
+    rng = np.random.default_rng(12)
+    k = rng.integers(1, 1 << 21, 400_000).astype(np.float64)
+    s = np.concatenate([rng.integers(1, 1 << 42, 2_000_000).astype(np.float64),
+                        k * k + k, k * k + k + 1, k * k - k + 1, k * k, k * k + 1,
+                        np.arange(0, 200_000, dtype=np.float64),
+                        (10 * k * k)[k < 600_000] * 0.1, (10 * k * k + 1)[k < 600_000] * 0.1])
+    g = ctx.raw_sqrt(s)
+    r = np.sqrt(s)
+    rel = np.abs(g - r) / np.maximum(r, 1e-300)
+    rel[s == 0] = np.abs(g[s == 0])
+    print("max relative error of v_sqrt_f64: 2^%.2f" % np.log2(max(rel.max(), 1e-300)))
+    assert rel.max() < 2.0 ** -24, rel.max()          # measured 2^-25.1 on MI355X; budget 2^-23
+    assert np.abs(g - r).max() < 0.125               # int_root() needs < 0.25

@@ -38,6 +38,12 @@ __global__ void k_dist_pairs(const double2 *__restrict__ coord, const int *__res
     out[t] = dist_xy<WT, INT>(a.x, a.y, b.x, b.y);
 }
 
+// self-test helper: the raw v_sqrt_f64 the integer-root variants build on
+__global__ void k_raw_sqrt(const double *__restrict__ in, int count, double *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[t] = __builtin_amdgcn_sqrt(in[t]);
+}
+
 // genetic.c:51-60 : one wave per permutation would leave the sum order free; the reference adds
 // edge by edge, so one block stages the edge lengths and thread 0 adds them in order when the
 // costs are not integer-valued.
@@ -136,7 +142,24 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
     // unknown types (the reference's parser leaves -1) use EUC_2D: src/distutil.c:90-91
     inst->wtype = (weight_type >= 0 && weight_type <= 5) ? weight_type : TSP_EUC_2D;
     inst->integer_cost = integer_cost ? 1 : 0;
+    inst->wtype_public = inst->wtype;
     inst->h_xy.assign(xy, xy + 2 * (size_t)n);
+    {   // integer coordinates of bounded span: switch to the exact integer-root variants (tsp_dist.hpp)
+        bool all_int = true;
+        double lox = xy[0], hix = xy[0], loy = xy[1], hiy = xy[1];
+        for (int v = 0; v < n; ++v) {
+            const double x = xy[2 * v], y = xy[2 * v + 1];
+            all_int = all_int && x == (double)(long long)x && y == (double)(long long)y && fabs(x) < 4.0e15 && fabs(y) < 4.0e15;
+            lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy;
+        }
+        const double span = sqrt((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
+        const char *off = getenv("TSP_NO_ICOORD");
+        if (all_int && span < TSP_ICOORD_MAX_DIST && !(off && *off == '1')) {
+            if (inst->wtype == TSP_EUC_2D && inst->integer_cost) inst->wtype = tsp::WT_EUC_2D_ICOORD;
+            else if (inst->wtype == TSP_ATT && inst->integer_cost) inst->wtype = tsp::WT_ATT_ICOORD;
+            else if (inst->wtype == TSP_CEIL_2D) { inst->wtype = tsp::WT_CEIL_2D_ICOORD; }
+        }
+    }
     std::vector<double2> c((size_t)n);
     for (int v = 0; v < n; ++v) {
         if (inst->wtype == TSP_GEO) { c[v].x = geo_radians(xy[2 * v]); c[v].y = geo_radians(xy[2 * v + 1]); }
@@ -181,6 +204,21 @@ int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
     (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o);
+    return TSP_OK;
+}
+
+int tsp_dev_selftest_raw_sqrt(tsp_dev_ctx *ctx, const double *in, int count, double *out) {
+    if (!ctx || !in || !out || count < 1) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    TSP_HIP_TRY(hipMalloc(&d_in, sizeof(double) * (size_t)count));
+    TSP_HIP_TRY(hipMalloc(&d_out, sizeof(double) * (size_t)count));
+    TSP_HIP_TRY(hipMemcpyAsync(d_in, in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_raw_sqrt, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_in, count, d_out);
+    TSP_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    TSP_HIP_TRY(hipGetLastError());
+    (void)hipFree(d_in); (void)hipFree(d_out);
     return TSP_OK;
 }
 

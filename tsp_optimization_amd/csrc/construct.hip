@@ -207,7 +207,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
 
 int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float *kernel_ms) {
     if (!inst) return TSP_DEV_E_ARG;
-    if (as_int32 && !inst->integer_cost && inst->wtype != TSP_CEIL_2D) return TSP_DEV_E_ARG;
+    if (as_int32 && !inst->integer_cost && inst->wtype_public != TSP_CEIL_2D) return TSP_DEV_E_ARG;
     const int n = inst->n;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;

@@ -16,7 +16,17 @@
 
 namespace tsp {
 
-enum : int { WT_EUC_2D = 0, WT_MAX_2D = 1, WT_MAN_2D = 2, WT_CEIL_2D = 3, WT_GEO = 4, WT_ATT = 5 };
+enum : int { WT_EUC_2D = 0, WT_MAX_2D = 1, WT_MAN_2D = 2, WT_CEIL_2D = 3, WT_GEO = 4, WT_ATT = 5,
+             // Same metrics on instances whose coordinates are all integers of bounded size: the
+             // squared distance s is then an exact integer and the rounded root can be fixed up
+             // exactly from a low-precision v_sqrt_f64 (see int_root below).  Chosen by the host
+             // (tsp_dev_inst_create) only when the bound holds; results are identical by construction.
+             WT_EUC_2D_ICOORD = 6, WT_CEIL_2D_ICOORD = 7, WT_ATT_ICOORD = 8 };
+
+// Largest coordinate span for which the *_ICOORD variants are used: distances < 2^21 keep
+// k*k, 10*k*k and s exact in fp64 and the raw v_sqrt_f64 error (<= 2^-23 relative per the ISA
+// manual) below 0.25, so rint() of it is within one of the true root.
+#define TSP_ICOORD_MAX_DIST 2097151.0
 
 // include/distutil.h:6-7
 #define TSP_GEO_PI 3.14159265358979323846264
@@ -32,13 +42,44 @@ __device__ __host__ __forceinline__ double geo_radians(double v) {
     return TSP_GEO_PI * (deg + 5.0 * frac / 3.0) / 180.0;
 }
 
+// Exact integer roots of an exact integer s >= 0 (s < 2^43) from the hardware's approximate sqrt:
+//   MODE 0: nint(sqrt(s))      = the k with k*k - k <  s <= k*k + k          (EUC_2D, integer costs)
+//   MODE 1: ceil(sqrt(s))      = the smallest k with k*k >= s                (CEIL_2D)
+//   MODE 2: ATT's rounded-up sqrt(s/10) = the smallest k with 10*k*k >= s    (ATT, integer costs;
+//           distutil.c:26-27 turns nint into a ceiling, and 10*k*k == s is exact in fp64)
+// g = v_sqrt_f64 of the (scaled) argument is within 0.25 of the true root r because r < 2^21 and the
+// instruction's relative error is <= 2^-23 (ISA manual; tests/test_gpu_parity.py measures it at
+// < 2^-25 on gfx950).  Then k0 = floor(g + c) is k* - 1 or k* (c = 0.25 for the rounded root,
+// 0.75 for the ceilings), and one exact residual test decides which.  No branch, 6 instructions.
+template <int MODE>
+__device__ __forceinline__ double int_root(double s) {
+    const double g = __builtin_amdgcn_sqrt(MODE == 2 ? s * 0.1 : s);
+    double k = floor(g + (MODE == 0 ? 0.25 : 0.75));
+    if constexpr (MODE == 0) {
+        const double e = fma(-k, k, s);            // exact: s - k^2
+        k += (e > k) ? 1.0 : 0.0;                  // s > k^2 + k: the root rounds to k + 1
+    } else if constexpr (MODE == 1) {
+        const double e = fma(-k, k, s);
+        k += (e > 0.0) ? 1.0 : 0.0;                // k^2 < s
+    } else {
+        const double e = fma(-10.0 * k, k, s);     // exact: s - 10 k^2
+        k += (e > 0.0) ? 1.0 : 0.0;
+    }
+    return k;
+}
+
 // Distance between two nodes given their coordinate pairs.  For WT_GEO the pairs are
 // (latitude, longitude) in radians as produced by geo_radians() at upload time; for every other
 // type they are the raw (x, y).  Unknown weight types fall back to EUC_2D (src/distutil.c:90-91),
 // which the host maps before choosing the template instance.
 template <int WT, bool INT>
 __device__ __forceinline__ double dist_xy(double ax, double ay, double bx, double by) {
-    if constexpr (WT == WT_ATT) {                       // src/distutil.c:20-31
+    if constexpr (WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD) {
+        static_assert(INT || WT == WT_CEIL_2D_ICOORD, "integer-coordinate variants exist for integer costs only");
+        const double dx = ax - bx, dy = ay - by;        // exact: integer operands
+        const double s = dx * dx + dy * dy;             // exact: < 2^43
+        return int_root<WT == WT_EUC_2D_ICOORD ? 0 : (WT == WT_CEIL_2D_ICOORD ? 1 : 2)>(s);
+    } else if constexpr (WT == WT_ATT) {                       // src/distutil.c:20-31
         const double dx = ax - bx, dy = ay - by;
         const double r = sqrt((dx * dx + dy * dy) / 10.0);
         if constexpr (!INT) return r;
@@ -81,6 +122,9 @@ __device__ __forceinline__ double dist_xy(double ax, double ay, double bx, doubl
             if (int__) call__(wt_c, std::true_type{}); else call__(wt_c, std::false_type{});  \
         };                                                                                    \
         switch (wt__) {                                                                       \
+        case tsp::WT_EUC_2D_ICOORD: call__(std::integral_constant<int, tsp::WT_EUC_2D_ICOORD>{}, std::true_type{}); break; \
+        case tsp::WT_CEIL_2D_ICOORD: call__(std::integral_constant<int, tsp::WT_CEIL_2D_ICOORD>{}, std::true_type{}); break; \
+        case tsp::WT_ATT_ICOORD: call__(std::integral_constant<int, tsp::WT_ATT_ICOORD>{}, std::true_type{}); break; \
         case tsp::WT_ATT: pick_int__(std::integral_constant<int, tsp::WT_ATT>{}); break;       \
         case tsp::WT_MAN_2D: pick_int__(std::integral_constant<int, tsp::WT_MAN_2D>{}); break; \
         case tsp::WT_MAX_2D: pick_int__(std::integral_constant<int, tsp::WT_MAX_2D>{}); break; \

@@ -51,7 +51,8 @@ struct tsp_dev_ctx {
 struct tsp_dev_inst {
     tsp_dev_ctx *ctx = nullptr;
     int n = 0;
-    int wtype = 0;        // mapped: unknown -> EUC_2D
+    int wtype = 0;        // kernel variant: unknown -> EUC_2D; *_ICOORD when the coordinates allow it
+    int wtype_public = 0; // the caller's weight type
     int integer_cost = 1;
     double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)

@@ -52,6 +52,7 @@ def lib():
         L.tsp_dev_inst_destroy.restype = None
         L.tsp_dev_inst_size.argtypes = [vp]
         L.tsp_dev_dist_pairs.argtypes = [vp, ip, ip, C.c_int, dp]
+        L.tsp_dev_selftest_raw_sqrt.argtypes = [vp, dp, C.c_int, dp]
         L.tsp_dev_dist_matrix.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float)]
         L.tsp_dev_construct.argtypes = [vp, C.c_int, C.c_int, ip, dp, ip, C.c_int, C.c_int64, dp, ip]
         L.tsp_dev_two_opt.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int64, dp,
@@ -81,7 +82,7 @@ def lib():
 EXPORTED = [
     "tsp_dev_open", "tsp_dev_close", "tsp_dev_last_error", "tsp_dev_count", "tsp_dev_synchronize",
     "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size",
-    "tsp_dev_dist_pairs", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_two_opt",
+    "tsp_dev_dist_pairs", "tsp_dev_selftest_raw_sqrt", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_two_opt",
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
@@ -118,6 +119,13 @@ class Context:
 
     def synchronize(self):
         _check(lib().tsp_dev_synchronize(self._h))
+
+    def raw_sqrt(self, x):
+        """The hardware's approximate v_sqrt_f64 (self-test of the integer-root variants' premise)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        _check(lib().tsp_dev_selftest_raw_sqrt(self._h, _d(x), len(x), _d(out)))
+        return out
 
     def close(self):
         if self._h:
