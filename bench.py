@@ -153,9 +153,9 @@ def main():
         tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tj):
             with open(tj) as f:
-                traffic = json.load(f).get("k_scan_best_n10000_hbm_bytes_per_launch")
+                traffic = json.load(f).get("k_step_best_n10000_hbm_bytes_per_launch")
         out["roofline"] = {
-            "kernel": "tsp::k_scan<EUC_2D, integer, BEST, RJ=2> (one sweep, n=10000)",
+            "kernel": "tsp::k_step<EUC_2D integer-coordinate variant, BEST, RJ=2> (one sweep + move, n=10000)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": ms, "evals_per_launch": evals_per_launch,
@@ -163,8 +163,10 @@ def main():
             "note": "achieved = evals/launch x 72 B (operands the reference touches per delta evaluation) / "
                     "kernel time; the tiled sweep re-uses operands on chip, so real HBM traffic (traffic) is "
                     "far below it and frac can exceed 1: the kernel is fp64-VALU bound, see DESIGN.md",
-            "valu": {"fp64_ops_per_eval": 70, "achieved_tflops": evals_per_launch * 70 / (ms * 1e-3) / 1e12,
-                     "peak_tflops_fp64_vector": 78.6},
+            "valu": {"fp64_instr_per_eval": 40, "achieved_tera_instr_per_s": evals_per_launch * 40 / (ms * 1e-3) / 1e12,
+                     "peak_tera_instr_per_s": 39.3,
+                     "note": "40 fp64-rate VALU instructions per evaluation in the integer-coordinate variant "
+                             "(k_step<6,...>); peak = 78.6 TFLOP/s vector fp64 / 2 (an FMA counts as 2 flops)"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:
@@ -188,6 +190,17 @@ def main():
             "recomputed_cost_match": bool(o2 == O.succ_cost(xy, wt, s2)), "sweeps": st2["sweeps"],
             "evals": st2["evals"], "moves": st2["moves"], "evals_per_s": st2["evals"] / dt2}
         out["time_to_local_optimum"] = extras
+        # the genuinely HBM-bound kernel of the path: n x n calc_dist matrix (4 n^2 bytes written)
+        _, dm_ms = inst.dist_matrix(as_int32=True, fetch=False)
+        _, dm64_ms = inst.dist_matrix(as_int32=False, fetch=False)
+        out["distance_matrix_build"] = {
+            "kernel": "tsp::k_dist_matrix (n=10000)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "int32": {"kernel_ms": dm_ms, "bytes_written": 4 * N_NODES * N_NODES,
+                      "achieved": 4 * N_NODES * N_NODES / (dm_ms * 1e-3) / 1e9,
+                      "frac": 4 * N_NODES * N_NODES / (dm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "f64": {"kernel_ms": dm64_ms, "bytes_written": 8 * N_NODES * N_NODES,
+                    "achieved": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9,
+                    "frac": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
