@@ -374,3 +374,69 @@ def test_raw_sqrt_error_budget_of_the_integer_variants(eng, ctx):
     print("max relative error of v_sqrt_f64: 2^%.2f" % np.log2(max(rel.max(), 1e-300)))
     assert rel.max() < 2.0 ** -24, rel.max()          # measured 2^-25.1 on MI355X; budget 2^-23
     assert np.abs(g - r).max() < 0.125               # int_root() needs < 0.25
+
+
+# ---- both execution engines give the reference's trajectory -----------------------------------
+@pytest.mark.parametrize("engine", [1, 2])          # TSP_ENGINE_GRID, TSP_ENGINE_LDS
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name,ic", [("berlin52", 1), ("pr299", 1), ("att532", 1), ("d493", 0), ("d493", 1),
+                                     ("dsj1000", 1), ("rand2000", 1)])
+def test_two_opt_engines_match_oracle(eng, ctx, engine, mode, name, ic):
+    if name == "rand2000" and mode == 1 and engine == 2:
+        pytest.skip("one workgroup for a 287-sweep n=2000 best-improvement descent: covered by the GRID engine")
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, ic)
+    _, succ0, obj0 = O.greedy(xy, wt, integer_cost=ic)
+    _check_two_opt(eng, inst, xy, wt, succ0, obj0, mode, integer_cost=ic, engine=engine)
+    inst.close()
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_two_opt_engines_random_tours_and_batches(eng, ctx, engine):
+    rng = np.random.default_rng(21)
+    for n in (5, 6, 17, 64, 65, 300, 1025):
+        xy = rng.integers(0, 3000, size=(n, 2)).astype(np.float64)
+        inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+        B = 3 if n <= 300 else 2
+        succ0 = np.stack([random_tour(n, rng) for _ in range(B)])
+        obj0 = np.array([O.succ_cost(xy, O.EUC_2D, s) for s in succ0])
+        for mode in ((eng.FIRST, eng.BEST) if n <= 300 else (eng.FIRST,)):   # the CPU side of BEST is O(n^3)
+            rc, s, o, st = inst.two_opt(succ0, obj0, mode=mode, engine=engine)
+            for b in range(B):
+                if mode == eng.FIRST:
+                    _, es, eo, est, _ = O.two_opt_first(xy, O.EUC_2D, succ0[b], obj0[b])
+                else:
+                    _, es, eo, est, _, _ = O.two_opt_best(xy, O.EUC_2D, succ0[b])
+                assert (s[b] == es).all() and o[b] == eo, (n, mode, b)
+                assert (st[b]["sweeps"], st[b]["evals"], st[b]["moves"], st[b]["reversed"]) == \
+                    (est["sweeps"], est["evals"], est["moves"], est["reversed"]), (n, mode, b)
+        inst.close()
+
+
+def test_lds_engine_rejects_tours_that_do_not_fit(eng, ctx):
+    xy = rand_instance(9000)
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    _, succ0, obj0 = O.greedy(xy, O.EUC_2D)
+    with pytest.raises(eng.TspDeviceError):
+        inst.two_opt(succ0, obj0, mode=eng.FIRST, engine=eng.ENGINE_LDS)
+    inst.close()
+
+
+def test_population_refinement_config5_spot_parity(eng, ctx):
+    """BASELINE config 5 (n=5000, population refined by alg_2opt), reduced to 6 individuals for the
+    test; 2 of them are checked against the oracle move for move (counters and final tour)."""
+    xy, wt = load_instance("rand5000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    O.srandom(123)
+    perms = np.stack([O.random_perm(len(xy)) for _ in range(6)])       # genetic.c:349-364
+    succ = np.stack([O.perm_to_succ(p) for p in perms])
+    cost = inst.perm_cost(perms)                                        # genetic.c:51-60
+    rc, s2, o2, st = inst.two_opt(succ, cost, mode=eng.FIRST)
+    inst.close()
+    for k in (0, 5):
+        assert cost[k] == O.perm_cost(xy, wt, perms[k])
+        _, es, eo, est, _ = O.two_opt_first(xy, wt, succ[k], cost[k])
+        assert (s2[k] == es).all() and o2[k] == eo
+        assert (st[k]["sweeps"], st[k]["evals"], st[k]["moves"]) == (est["sweeps"], est["evals"], est["moves"])
+    for k in range(6):
+        assert O.is_tour(s2[k]) and o2[k] == O.succ_cost(xy, wt, s2[k])

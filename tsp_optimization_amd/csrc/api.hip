@@ -11,8 +11,7 @@ using namespace tsp;
 // implemented in two_opt_grid.hip / two_opt_lds.hip
 int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure, int64_t max_steps,
                  double time_limit_s, int sync, int *all_done);
-int tsp_lds_two_opt(tsp_dev_inst *inst, int mode, int B, int *succ, int succ_stride, int64_t tour_stride,
-                    double *obj, double time_limit_s, tsp_two_opt_stats *stats);
+int tsp_lds_run(tsp_dev_tours *t, int mode, double time_limit_s, int *all_done);
 bool tsp_lds_fits(const tsp_dev_inst *inst);
 
 namespace tsp {
@@ -253,10 +252,17 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
                     int64_t tour_stride, double *obj, double time_limit_s, tsp_two_opt_stats *stats) {
     if (!inst || !succ || !obj || B < 1 || succ_stride < 1) return TSP_DEV_E_ARG;
     if (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST) return TSP_DEV_E_ARG;
-    if (engine == TSP_ENGINE_AUTO) engine = TSP_ENGINE_GRID;
-    if (engine == TSP_ENGINE_LDS) {
-        if (!tsp_lds_fits(inst)) return TSP_DEV_E_ARG;
-        return tsp_lds_two_opt(inst, mode, B, succ, succ_stride, tour_stride, obj, time_limit_s, stats);
+    if (engine != TSP_ENGINE_AUTO && engine != TSP_ENGINE_GRID && engine != TSP_ENGINE_LDS) return TSP_DEV_E_ARG;
+    if (engine == TSP_ENGINE_LDS && !tsp_lds_fits(inst)) return TSP_DEV_E_ARG;
+    if (engine == TSP_ENGINE_AUTO) {
+        // One workgroup per tour (state in LDS, no launch per step) wins when there are several tours
+        // or the tour is small; one big tour wants the whole chip per step.  Results are identical.
+        const char *force = getenv("TSP_ENGINE");
+        const bool lds_ok = tsp_lds_fits(inst);
+        bool lds = lds_ok && (mode == TSP_2OPT_FIRST ? (B >= 4 || inst->n <= 3000) : inst->n <= 1500);
+        if (force && *force == '1') lds = false;
+        if (force && *force == '2' && lds_ok) lds = true;
+        engine = lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID;
     }
     const double t0 = wall_s();
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
@@ -271,7 +277,8 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     TSP_HIP_TRY(hipEventCreate(&e1));
     TSP_HIP_TRY(hipEventRecord(e0, s));
     int done = 0;
-    int status = tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
+    int status = engine == TSP_ENGINE_LDS ? tsp_lds_run(t, mode, time_limit_s, &done)
+                                          : tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
     TSP_HIP_TRY(hipEventRecord(e1, s));
     TSP_HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;

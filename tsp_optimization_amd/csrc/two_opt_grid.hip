@@ -661,6 +661,17 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     return status;
 }
 
+// After another engine has rewritten order[] (two_opt_lds.hip): rebuild pos[], and give BEST runs
+// that were cut short their recomputed cost (tabusearch.c:168-172).
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
+    hipStream_t s = t->inst->ctx->stream;
+    hipLaunchKernelGGL(k_build_pos, dim3((t->n + 255) / 256, t->B), dim3(256), 0, s, t->d_order, t->d_pos, t->n);
+    if (timed_out && mode == TSP_2OPT_BEST) launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    return TSP_OK;
+}
+
 extern "C" {
 
 int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
@@ -668,9 +679,25 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     tsp_dev_tours *t = new tsp_dev_tours();
     t->inst = inst; t->B = B; t->n = inst->n;
-    t->first_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_FIRST_ROWS_PER_BLOCK", 8)));
-    t->first_min_rows = std::max(1, env_int("TSP_FIRST_MIN_ROWS", 32));
+    // FIRST-mode chunk geometry.  A step costs a launch (~10 us of latency) plus the evaluation of
+    // rows x n pairs per tour; only the pairs up to the first improving one are useful.  One tour:
+    // latency dominates, 32 rows is the measured optimum at n = 10000.  Many tours: keep the smallest
+    // chunk near 2M pairs per launch so that dense-improvement phases do not pay for rows they discard.
+    const long long pairs_budget = 2000000;
+    int auto_min = (int)std::min<long long>(32, std::max<long long>(4, pairs_budget / ((long long)B * inst->n)));
+    auto_min = auto_min >= 32 ? 32 : (auto_min >= 16 ? 16 : (auto_min >= 8 ? 8 : 4));
+    t->first_min_rows = std::max(1, env_int("TSP_FIRST_MIN_ROWS", auto_min));
+    t->first_rows_per_block =
+        std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_FIRST_ROWS_PER_BLOCK", std::min(8, t->first_min_rows))));
     t->first_max_rows = std::max(t->first_min_rows, env_int("TSP_FIRST_MAX_ROWS", 2048));
+    {   // Every launch dispatches the grid of the LARGEST chunk (blocks beyond a tour's current chunk
+        // return at once, but dispatching them is not free): with many tours keep that grid near
+        // 16k blocks so that a step stays latency-sized.
+        const long long gx = (inst->n + kScanThreads * kFirstRJ - 1) / (kScanThreads * kFirstRJ);
+        const long long budget = std::max<long long>(1, 16384 / (gx * B));
+        const int cap = (int)std::max<long long>(t->first_min_rows, budget * t->first_rows_per_block);
+        t->first_max_rows = std::min(t->first_max_rows, cap);
+    }
     t->best_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_BEST_ROWS_PER_BLOCK", 32)));
     t->count_evals = env_int("TSP_COUNT_EVALS", 1);
     const size_t bn = (size_t)B * inst->n;

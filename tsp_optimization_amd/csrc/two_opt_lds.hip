@@ -1,15 +1,262 @@
-// two_opt_lds.hip -- LDS engine: one workgroup per tour, the whole 2-opt descent in one launch.
-#include "tsp_internal.hpp"
+// two_opt_lds.hip -- LDS engine: one 1024-thread workgroup per tour, the whole 2-opt descent inside
+// one launch.  Same semantics, same control block and same counters as the GRID engine
+// (two_opt_grid.hip); what changes is where the state lives and who synchronises:
+//
+//   LDS (160 KiB per CU on MI355X):  coord[n] double2 | order[n], pos[n] uint16 | 32 row records
+//   => 20 n bytes + 2.5 KiB: tours of up to ~8000 nodes stay on chip for the entire descent; a
+//   step costs two block barriers instead of a kernel boundary, so the many-small-tours cases
+//   (GRASP multi-start, population refinement) are no longer launch-latency bound.
+//
+// Per step the block scans rows [ci, ci+R) (FIRST, R adaptive 1..32) or every row in blocks of 32
+// (BEST): lanes own columns j = tid + 1024 m, derive the column's NodeRec from LDS once per row
+// block and evaluate it against the row records (LDS broadcast).  The winner is a block arg-min;
+// the move is a parallel swap loop on the LDS arrays.
+#include "two_opt_common.hpp"
+
+#include <algorithm>
+#include <time.h>
 
 #pragma clang fp contract(off)
 
+namespace tsp {
+
+constexpr int kLdsThreads = 1024;
+constexpr int kLdsRows = 32;
+using idx_t = unsigned short;
+
+__host__ __device__ inline size_t lds_bytes_needed(int n) {
+    // rows | coord | order | pos | reduction scratch
+    return sizeof(NodeRec) * kLdsRows + sizeof(double2) * (size_t)n + 2 * sizeof(idx_t) * (size_t)n + 1024;
+}
+
+template <int WT, bool INT, int MODE>
+__global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
+                                                             int *__restrict__ orders_g,
+                                                             TourState *__restrict__ states, int n, int rmin,
+                                                             int rmax, int count_evals, int max_iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
+    double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
+    idx_t *order = reinterpret_cast<idx_t *>(coord + n);
+    idx_t *pos = order + n;
+    char *scratch = reinterpret_cast<char *>(pos + n);
+    scratch += (16 - (reinterpret_cast<size_t>(scratch) & 15)) & 15;
+    double *s_d = reinterpret_cast<double *>(scratch);            // 16
+    u64 *s_k = reinterpret_cast<u64 *>(scratch + 128);            // 16
+    long long *s_ll = reinterpret_cast<long long *>(scratch + 256);  // 16
+    double *s_chunk = reinterpret_cast<double *>(scratch + 384);  // 64 doubles (fcost cost recompute)
+
+    const int tour = blockIdx.x;
+    const int tid = threadIdx.x;
+    TourState *st = states + tour;
+    if (st->done) return;
+    int *order_g = orders_g + (size_t)tour * n;
+
+    for (int v = tid; v < n; v += kLdsThreads) {
+        coord[v] = coord_g[v];
+        const int w = order_g[v];
+        order[v] = (idx_t)w;
+        pos[w] = (idx_t)v;
+    }
+    // control block in registers (every thread keeps an identical copy)
+    int ci = st->ci, cj = st->cj, chunk = min(max(st->chunk_rows, 1), kLdsRows), done = 0;
+    double obj = st->obj, seen = st->seen_cost;
+    long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
+              scanned = st->pairs_scanned, steps = st->steps;
+    __syncthreads();
+
+    for (int iter = 0; iter < max_iters && !done; ++iter) {
+        int row_lo = 0, row_hi = n - 1;
+        if constexpr (MODE == TSP_2OPT_FIRST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
+
+        // ---- scan ------------------------------------------------------------------------------
+        double bd = 0.0;
+        u64 key = kNoKey;
+        for (int rb = row_lo; rb < row_hi; rb += kLdsRows) {
+            const int nr = min(kLdsRows, row_hi - rb);
+            __syncthreads();
+            if (tid < nr) s_rows[tid] = load_node<WT, INT>(coord, order, pos, n, rb + tid);
+            __syncthreads();
+            for (int j = tid; j < n; j += kLdsThreads) {
+                if (j <= rb) continue;  // no row of this block is below column j
+                const NodeRec rj = load_node<WT, INT>(coord, order, pos, n, j);
+                for (int r = 0; r < nr; ++r) {
+                    const int i = rb + r;
+                    const NodeRec ri = s_rows[r];
+                    bool ok = j > i && j != ri.succ && rj.succ != i;  // heuristics.c:471 / tabusearch.c:134
+                    if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
+                    const double delta = pair_delta<WT, INT>(ri, rj);
+                    const u64 k = make_key(i, j);
+                    if constexpr (MODE == TSP_2OPT_FIRST) {
+                        if (ok && delta < 0 && k < key) { bd = delta; key = k; }
+                    } else {
+                        if (ok && better(delta, k, bd, key)) { bd = delta; key = k; }
+                    }
+                }
+            }
+        }
+        block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
+        const bool found = key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0);
+        const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
+
+        // ---- reference-equivalent evaluation count (FIRST) -----------------------------------------
+        long long adj = 0;
+        int ni = wi, nj = wj;
+        if constexpr (MODE == TSP_2OPT_FIRST) {
+            if (!found) { ni = row_hi - 1; nj = n - 1; }
+            if (count_evals) {
+                const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
+                long long c = 0;
+                for (int r = ci + tid; r <= ni; r += kLdsThreads) {
+                    const int p = pos[r];
+                    const int s = order[p + 1 == n ? 0 : p + 1], q = order[p == 0 ? n - 1 : p - 1];
+                    const u64 ks = make_key(r, s), kq = make_key(r, q);
+                    c += (s > r && ks > lo && ks <= hi) ? 1 : 0;
+                    c += (q > r && kq > lo && kq <= hi) ? 1 : 0;
+                }
+                adj = block_sum<long long>(c, s_ll);
+            }
+        }
+
+        // ---- move: reverse positions pa+1 .. pb (cyclic) --------------------------------------------
+        int L = 0;
+        if (found) {
+            const int pa = pos[wi], pb = pos[wj];
+            __syncthreads();  // everyone has read pa/pb (and finished the adjacency reads)
+            L = pb - pa; if (L < 0) L += n;
+            const int half = L >> 1;
+            for (int t = tid; t < half; t += kLdsThreads) {
+                int p = pa + 1 + t; if (p >= n) p -= n;
+                int q = pb - t; if (q < 0) q += n;
+                const idx_t u = order[p], w = order[q];
+                order[p] = w; order[q] = u;
+                pos[w] = (idx_t)p; pos[u] = (idx_t)q;
+            }
+        }
+        __syncthreads();
+
+        // ---- control block ----------------------------------------------------------------------------
+        steps += 1;
+        if constexpr (MODE == TSP_2OPT_BEST) {
+            sweeps += 1;
+            evals += (long long)n * (n - 1) / 2 - n;
+            scanned += (long long)n * (n - 1) / 2;
+            if (found) { moves += 1; reversed += L - 1; }
+            else {
+                done = 1;
+                // recomputed cost, node order (tabusearch.c:168-172)
+                if constexpr (INT || WT == WT_CEIL_2D) {
+                    double c = 0.0;
+                    for (int v = tid; v < n; v += kLdsThreads) c += load_node<WT, INT>(coord, order, pos, n, v).ds;
+                    obj = block_sum<double>(c, s_d);
+                } else {
+                    double acc = 0.0;
+                    for (int base = 0; base < n; base += 64) {  // sequential order, 64 edges at a time
+                        __syncthreads();
+                        if (tid < 64 && base + tid < n) s_chunk[tid] = load_node<WT, INT>(coord, order, pos, n, base + tid).ds;
+                        __syncthreads();
+                        const int m = min(64, n - base);
+                        for (int t = 0; t < m; ++t) acc += s_chunk[t];  // every thread adds the same values in order
+                    }
+                    obj = acc;
+                }
+            }
+        } else {
+            const long long r_old = pair_rank(ci, cj, n);
+            scanned += pair_rank(row_hi - 1, n - 1, n) - r_old;
+            evals += pair_rank(ni, nj, n) - r_old - adj;
+            if (found) {
+                obj += bd;                              // heuristics.c:486
+                moves += 1; reversed += L - 1;
+                ci = wi; cj = wj; chunk = rmin;
+            } else {
+                chunk = min(chunk * 2, rmax);
+                if (row_hi >= n - 1) {                  // sweep complete
+                    sweeps += 1;
+                    if (obj >= seen) done = 1;          // heuristics.c:492
+                    else { seen = obj; ci = 0; cj = 0; }
+                } else { ci = row_hi - 1; cj = n - 1; }
+            }
+        }
+    }
+
+    // ---- write back ---------------------------------------------------------------------------------------
+    __syncthreads();
+    for (int v = tid; v < n; v += kLdsThreads) order_g[v] = (int)order[v];
+    if (tid == 0) {
+        st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
+        st->sweeps = sweeps; st->evals = evals; st->moves = moves; st->reversed = reversed;
+        st->pairs_scanned = scanned; st->steps = steps;
+    }
+}
+
+}  // namespace tsp
+
 using namespace tsp;
 
-bool tsp_lds_fits(const tsp_dev_inst *inst) { (void)inst; return false; }
+namespace {
+double wall_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
-int tsp_lds_two_opt(tsp_dev_inst *inst, int mode, int B, int *succ, int succ_stride, int64_t tour_stride,
-                    double *obj, double time_limit_s, tsp_two_opt_stats *stats) {
-    (void)inst; (void)mode; (void)B; (void)succ; (void)succ_stride; (void)tour_stride; (void)obj;
-    (void)time_limit_s; (void)stats;
-    return TSP_DEV_E_ARG;
+template <int WT, bool INT>
+hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_iters) {
+    hipStream_t s = t->inst->ctx->stream;
+    const size_t bytes = lds_bytes_needed(t->n);
+    hipError_t e;
+    if (mode == TSP_2OPT_FIRST) {
+        auto k = k_lds_two_opt<WT, INT, TSP_2OPT_FIRST>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
+                           rmin, rmax, t->count_evals, max_iters);
+    } else {
+        auto k = k_lds_two_opt<WT, INT, TSP_2OPT_BEST>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
+                           rmin, rmax, t->count_evals, max_iters);
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+// implemented in two_opt_grid.hip
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+
+bool tsp_lds_fits(const tsp_dev_inst *inst) {
+    return inst && inst->n <= 65535 && lds_bytes_needed(inst->n) <= (size_t)160 * 1024;
+}
+
+// Runs the tours of `t` to their local optima with the LDS engine (launches of bounded length so
+// that a time limit can be honoured between them).
+int tsp_lds_run(tsp_dev_tours *t, int mode, double time_limit_s, int *all_done) {
+    if (!t || !tsp_lds_fits(t->inst)) return TSP_DEV_E_ARG;
+    hipStream_t s = t->inst->ctx->stream;
+    const double t0 = wall_s();
+    const int rmin = std::max(1, std::min(kLdsRows, env_int("TSP_LDS_MIN_ROWS", 2)));
+    const int rmax = kLdsRows;
+    const int max_iters = mode == TSP_2OPT_FIRST ? 8192 : 256;
+    if (all_done) *all_done = 0;
+    int status = TSP_OK;
+    for (;;) {
+        hipError_t e = hipSuccess;
+        TSP_DISPATCH_METRIC(t->inst->wtype, t->inst->integer_cost, { e = launch_lds<WTC, INTC>(t, mode, rmin, rmax, max_iters); });
+        if (e != hipSuccess) { tsp::set_last_error("k_lds_two_opt launch", e, __FILE__, __LINE__); return TSP_DEV_E_HIP; }
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        bool done = true;
+        for (int b = 0; b < t->B; ++b) done = done && t->h_state[b].done;
+        if (done) { if (all_done) *all_done = 1; break; }
+        if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
+    }
+    // pos[] in HBM follows the order[] written back; BEST stopped early gets its recomputed cost
+    const int rc = tsp_grid_after_external_run(t, mode, status == TSP_TIME_LIMIT_EXCEEDED);
+    return rc ? rc : status;
 }
