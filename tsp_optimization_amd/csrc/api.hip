@@ -255,11 +255,13 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     if (engine != TSP_ENGINE_AUTO && engine != TSP_ENGINE_GRID && engine != TSP_ENGINE_LDS) return TSP_DEV_E_ARG;
     if (engine == TSP_ENGINE_LDS && !tsp_lds_fits(inst)) return TSP_DEV_E_ARG;
     if (engine == TSP_ENGINE_AUTO) {
-        // One workgroup per tour (state in LDS, no launch per step) wins when there are several tours
-        // or the tour is small; one big tour wants the whole chip per step.  Results are identical.
+        // Measured on MI355X (tools/gpu_latency.py, tools/gpu_configs.py): a single tour is always
+        // faster with the whole chip per step (GRID), and BEST batches are a perfect fit for GRID's
+        // grid.z = tour; one workgroup per tour (LDS) wins for FIRST descents of several tours, whose
+        // steps would otherwise be launch-latency bound in lockstep.  Results are identical.
         const char *force = getenv("TSP_ENGINE");
         const bool lds_ok = tsp_lds_fits(inst);
-        bool lds = lds_ok && (mode == TSP_2OPT_FIRST ? (B >= 4 || inst->n <= 3000) : inst->n <= 1500);
+        bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
         if (force && *force == '1') lds = false;
         if (force && *force == '2' && lds_ok) lds = true;
         engine = lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID;
