@@ -204,18 +204,16 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        sweeps = 10
+        sweeps = 25
         _, es, eo = O.greedy(xy, wt, start=start_node)
         assert eo == obj0[0] and (es == succ0[0]).all()
         _, _, _, cst, _, _ = O.two_opt_best(xy, wt, es, max_sweeps=sweeps)
-        first_sample = 60_000_000
         out["cpu_baseline"] = {
             "value": cst["evals"] / cst["seconds"], "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": "%d best-improvement sweeps (%d delta evaluations) of the same rand10000 greedy tour by "
                       "oracle/tsp_oracle.c (gcc -O2), one thread, %.1f s; the reference is single-threaded and "
                       "cannot be built here (needs cplex.h)" % (sweeps, cst["evals"], cst["seconds"]),
         }
-        del first_sample
 
     if rank == 0:
         print(json.dumps(out))

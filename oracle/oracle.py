@@ -69,6 +69,10 @@ def lib():
         L.orc_succ_to_perm.argtypes = [C.c_int, ip, ip]
         L.orc_random_perm.argtypes = [C.c_int, ip]
         L.orc_udir_pos.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_vns_kick.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
+        L.orc_vns.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong, C.POINTER(C.c_longlong)]
+        L.orc_tabu.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong,
+                               C.POINTER(C.c_longlong)]
         L.orc_srandom.argtypes = [C.c_uint]
         L.orc_urand.restype = C.c_double
         L.orc_parse_tsplib.argtypes = [C.c_char_p, dp, C.c_int, ip]
@@ -186,6 +190,35 @@ def two_opt_best(xy, wtype, succ, obj=0.0, integer_cost=1, tabu=None, iter_=1, t
                                     tenure, _i(prev) if want_prev else None, time_limit, max_sweeps,
                                     C.byref(st), tr, trace_cap)
     return status, succ, o.value, st.as_dict(), _trace_out(tr, st.moves, trace_cap), prev
+
+
+def vns_kick(xy, wtype, succ, integer_cost=1):
+    """-> (succ', obj') after one kick (draws from libc random())"""
+    xy = _xy(xy)
+    succ = np.array(succ, dtype=np.int32, copy=True)
+    o = C.c_double(0)
+    lib().orc_vns_kick(_d(xy), len(xy), wtype, integer_cost, _i(succ), C.byref(o))
+    return succ, o.value
+
+
+def vns(xy, wtype, succ, obj, rounds, integer_cost=1):
+    """-> (succ', obj', rounds that improved the incumbent)"""
+    xy = _xy(xy)
+    succ = np.array(succ, dtype=np.int32, copy=True)
+    o = C.c_double(obj)
+    imp = C.c_longlong(0)
+    lib().orc_vns(_d(xy), len(xy), wtype, integer_cost, _i(succ), C.byref(o), rounds, C.byref(imp))
+    return succ, o.value, imp.value
+
+
+def tabu(xy, wtype, succ, obj, iterations, policy=0, integer_cost=1):
+    """-> (succ', obj', total best-improvement moves)"""
+    xy = _xy(xy)
+    succ = np.array(succ, dtype=np.int32, copy=True)
+    o = C.c_double(obj)
+    mv = C.c_longlong(0)
+    lib().orc_tabu(_d(xy), len(xy), wtype, integer_cost, policy, _i(succ), C.byref(o), iterations, C.byref(mv))
+    return succ, o.value, mv.value
 
 
 def perm_cost(xy, wtype, perm, integer_cost=1):

@@ -321,6 +321,97 @@ int orc_two_opt_best(const double *xy, int n, int wtype, int integer_cost, int *
     return status;
 }
 
+/* ---- meta-heuristic drivers around the two 2-opt loops ---------------------------------------- */
+
+static int rand_in(int from, int to) { return from + (int)(orc_urand() * (to - from)); } /* src/utility.c:752 */
+
+/* src/vns.c:11-100 */
+void orc_vns_kick(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj) {
+    int *tour = malloc(sizeof(int) * (size_t)n);
+    orc_succ_to_perm(n, succ, tour);
+    int p1 = rand_in(0, n), p2 = p1, p3 = p1;
+    while (p2 == p1 || abs(p1 - p2) <= 1) p2 = rand_in(0, n);                                   /* :28-30 */
+    while (p3 == p1 || p3 == p2 || abs(p1 - p3) <= 1 || abs(p2 - p3) <= 1) p3 = rand_in(0, n);  /* :31-33 */
+    int t;
+    if (p1 > p2) { t = p1; p1 = p2; p2 = t; }
+    if (p1 > p3) { t = p1; p1 = p3; p3 = t; }
+    if (p2 > p3) { t = p2; p2 = p3; p3 = t; }
+    const int a = tour[p1], b = tour[p1 + 1], c = tour[p2], d = tour[p2 + 1], e = tour[p3];
+    const int f = tour[p3 + 1 == n ? 0 : p3 + 1];  /* the reference reads tour[n] here when p3 == n-1 */
+    succ[a] = d; succ[e] = b; succ[c] = f;                                                      /* :60-62 */
+    orc_succ_to_perm(n, succ, tour);
+    *obj = orc_perm_cost(xy, n, wtype, integer_cost, tour);                                     /* :77-86 */
+    free(tour);
+}
+
+/* src/vns.c:103-166 */
+int orc_vns(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj, long long rounds,
+            long long *improved) {
+    int *best = malloc(sizeof(int) * (size_t)n);
+    memcpy(best, succ, sizeof(int) * (size_t)n);
+    double best_obj = *obj;
+    long long better = 0;
+    for (long long r = 0; r < rounds; r++) {
+        orc_vns_kick(xy, n, wtype, integer_cost, succ, obj);
+        orc_two_opt_first(xy, n, wtype, integer_cost, succ, obj, -1.0, 0, NULL, NULL, 0);
+        if (*obj < best_obj) { best_obj = *obj; memcpy(best, succ, sizeof(int) * (size_t)n); better++; }
+        *obj = best_obj;                                                                        /* :157-158 */
+        memcpy(succ, best, sizeof(int) * (size_t)n);
+    }
+    free(best);
+    if (improved) *improved = better;
+    return ORC_OK;
+}
+
+/* src/tabusearch.c:188-320 */
+int orc_tabu(const double *xy, int n, int wtype, int integer_cost, int policy, int *succ, double *obj,
+             long long iterations, long long *total_moves) {
+    const long long cols = (long long)n * (n - 1) / 2;
+    int *stamp = calloc((size_t)cols, sizeof(int));
+    int *prev = calloc((size_t)n, sizeof(int));
+    int *best = calloc((size_t)n, sizeof(int));
+    double best_obj = DBL_MAX;
+    int lo = (int)ceil(n * 0.02), hi = (int)round(n * 0.1);                                     /* :213-214 */
+    if (lo == hi) hi += 2; else if (hi < lo) { int t = lo; lo = hi; hi = t; }
+    int tenure = lo, rising = 0;
+    long long moved = 0;
+    for (int it = 1; it <= iterations; it++) {
+        orc_stats st;
+        orc_two_opt_best(xy, n, wtype, integer_cost, succ, obj, stamp, it, tenure, prev, -1.0, -1, &st, NULL, 0);
+        moved += st.moves;
+        if (*obj < best_obj) { best_obj = *obj; memcpy(best, succ, sizeof(int) * (size_t)n); }
+        int a, b, a1, b1;
+        for (;;) {                                                                              /* :262-287 */
+            a = rand_in(0, n); b = rand_in(0, n);
+            a1 = succ[a]; b1 = succ[b];
+            if (a == b || a1 == b || b1 == a) continue;
+            if (!stamp_is_tabu(&stamp[orc_udir_pos(a, a1, n)], it, tenure) &&
+                !stamp_is_tabu(&stamp[orc_udir_pos(b, b1, n)], it, tenure) &&
+                !stamp_is_tabu(&stamp[orc_udir_pos(a, b, n)], it, tenure) &&
+                !stamp_is_tabu(&stamp[orc_udir_pos(a1, b1, n)], it, tenure)) break;
+        }
+        succ[a] = b; succ[a1] = b1;
+        reverse_walk(n, succ, b, a1, prev);
+        if (policy == 0) {                                                                      /* :33-37 */
+            if (it % 100 == 0) tenure = (tenure == lo) ? hi : lo;
+        } else if (policy == 1) {                                                               /* :47-59 */
+            if (tenure > hi) tenure = hi;
+            if (tenure < lo) tenure = lo;
+            if (tenure == hi || tenure == lo) rising = !rising;
+            if (rising) tenure++; else tenure--;
+        } else {                                                                                /* :69-72 */
+            if (it == 1 || it % 100 == 0) tenure = rand_in(lo, hi + 1);
+        }
+        stamp[orc_udir_pos(a, a1, n)] = it;                                                     /* :306-309 */
+        stamp[orc_udir_pos(b, b1, n)] = it;
+    }
+    *obj = best_obj;
+    memcpy(succ, best, sizeof(int) * (size_t)n);
+    free(stamp); free(prev); free(best);
+    if (total_moves) *total_moves = moved;
+    return ORC_OK;
+}
+
 /* ---- tour cost / representation -------------------------------------------------------- */
 
 /* src/genetic.c:51-60 */

@@ -14,6 +14,10 @@
  * NOT buildable in this image (every source includes <cplex.h>, which the image
  * lacks, and stand-in headers are not allowed), so there is no oracle/_ref.
  *
+ * The two driver restatements (orc_vns, orc_tabu) are pinned only through their components
+ * (orc_two_opt_first / orc_two_opt_best / orc_perm_cost): the reference's loops run until a wall-clock
+ * limit, so neither its result tables nor any fixture can pin the loops themselves.
+ *
  * Every function cites the reference file:line whose behaviour it restates.
  * Data is passed as flat arrays (xy = n x {x,y} doubles, succ = successor list)
  * rather than the reference's `instance` struct.
@@ -88,6 +92,22 @@ void orc_random_perm(int n, int *perm);
 
 /* src/utility.c:17-30 */
 int orc_udir_pos(int i, int j, int n);
+
+/* src/vns.c:11-100 : random 3-edge reconnection + full cost recompute; draws from libc random().
+ * The reference reads tour[idx3+1] one past its array when idx3 == n-1 (:57); this restatement
+ * (like the product) wraps that index to the tour's first node. */
+void orc_vns_kick(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj);
+
+/* src/vns.c:103-166 with the initial solution passed in (the reference builds it with
+ * HEU_2opt_greedy_iter, :116) and a harness cap on the number of kick+2opt rounds instead of the
+ * wall clock.  improved (may be NULL) counts the rounds that lowered the incumbent. */
+int orc_vns(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj, long long rounds,
+            long long *improved);
+
+/* src/tabusearch.c:188-320 with the initial solution passed in (:200) and a cap on the number of
+ * iterations instead of the wall clock.  policy: 0 = step (:33), 1 = linear (:47), 2 = random (:69). */
+int orc_tabu(const double *xy, int n, int wtype, int integer_cost, int policy, int *succ, double *obj,
+             long long iterations, long long *total_moves);
 
 /* libc RNG access so that tests can reproduce the reference's stream (src/solver.c:264-266) */
 void orc_srandom(unsigned seed);

@@ -62,6 +62,9 @@ def host():
     L.HEU_2opt_grasp_multistart.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.tsp_host_last_stats.argtypes = [C.POINTER(C.c_longlong)] * 3 + [C.POINTER(C.c_double)]
+    L.kick.argtypes = [C.POINTER(Instance)]
+    L.tsp_host_vns.argtypes = [C.POINTER(Instance), C.c_longlong]
+    L.tsp_host_tabu.argtypes = [C.POINTER(Instance), C.c_int, C.c_longlong]
     yield L
     L.tsp_host_shutdown()
 
@@ -181,6 +184,62 @@ def test_multistart_256_matches_golden_table_and_shards(host):
         results.append((cost.value, start.value))
     assert results[0] == (exp["best_true"], exp["best_start"])
     assert min(results[1:]) == results[0]                          # what the all-reduce(min) would return
+
+
+# ---- the meta-heuristic drivers around the two 2-opt loops ---------------
+def _initial(h):
+    """What both drivers start from: HEU_2opt_greedy_iter (vns.c:116, tabusearch.c:200)."""
+    _, s0, o0 = O.greedy_iter(h.xy, h.wt)
+    _, s1, o1, _, _ = O.two_opt_first(h.xy, h.wt, s0, o0)
+    return s1, o1
+
+
+def test_vns_kick_matches_oracle(host):
+    h = HostInstance("pr299")
+    s1, o1 = _initial(h)
+    for seed in (1, 2, 3, 99):
+        h.set_tour(s1, o1)
+        O.srandom(seed)
+        assert host.kick(C.byref(h.c)) == 0
+        O.srandom(seed)
+        es, eo = O.vns_kick(h.xy, h.wt, s1)
+        assert (h.succ == es).all() and h.obj == eo and O.is_tour(h.succ)
+
+
+@pytest.mark.parametrize("name,rounds", [("pr299", 40), ("att532", 12)])
+def test_vns_rounds_match_oracle(host, name, rounds):
+    """HEU_VNS with the round cap: same incumbent tour and cost as the oracle's restatement of vns.c:103-166."""
+    h = HostInstance(name)
+    h.c.params.time_limit = 600
+    O.srandom(123)
+    rc = host.tsp_host_vns(C.byref(h.c), rounds)
+    s1, o1 = _initial(h)
+    O.srandom(123)
+    es, eo, improved = O.vns(h.xy, h.wt, s1, o1, rounds)
+    assert rc == 0 and h.obj == eo and (h.succ == es).all()
+    assert eo <= o1 and h.obj == O.succ_cost(h.xy, h.wt, h.succ)
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_tabu_iterations_match_oracle(host, policy):
+    """tabu() (tabusearch.c:188-320) with the iteration cap: device-resident stamps, host RNG, same kicks."""
+    h = HostInstance("pr299")
+    h.c.params.time_limit = 600
+    O.srandom(123)
+    rc = host.tsp_host_tabu(C.byref(h.c), policy, 120)
+    s1, o1 = _initial(h)
+    O.srandom(123)
+    es, eo, moves = O.tabu(h.xy, h.wt, s1, o1, 120, policy)
+    assert rc == 0 and h.obj == eo and (h.succ == es).all() and moves > 0
+    assert h.obj == O.succ_cost(h.xy, h.wt, h.succ)
+
+
+def test_cli_vns_and_tabu_respect_the_time_limit():
+    f = os.path.join(INSTANCES, "pr299.tsp")
+    for m in ("VNS", "TABU_LIN"):
+        out = run_cli(["-f", f, "-method", m, "-seed", "123", "-t", "1", "--perfprof", "-verbose", "-1"])
+        cost = float(out.strip().split()[-1])
+        assert 48191 <= cost <= 51956        # between the optimum and the 2OPT_GREEDY_ITER start
 
 
 # ---- the CLI -------------------------------------------------------------------------------------

@@ -821,14 +821,15 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     TSP_HIP_TRY(hipEventCreate(&e1));
     double total = 0.0;
     launch_arm(t, TSP_2OPT_BEST);
-    for (int r = 0; r < reps; ++r) {
-        TSP_HIP_TRY(hipEventRecord(e0, s));
-        launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);
-        TSP_HIP_TRY(hipEventRecord(e1, s));
-        TSP_HIP_TRY(hipEventSynchronize(e1));
+    launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);   // warm
+    TSP_HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);   // back to back on the engine's stream
+    TSP_HIP_TRY(hipEventRecord(e1, s));
+    TSP_HIP_TRY(hipEventSynchronize(e1));
+    {
         float ms = 0.f;
         TSP_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        total += ms;
+        total = ms;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (mean_ms) *mean_ms = (float)(total / reps);

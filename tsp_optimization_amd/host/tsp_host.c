@@ -317,6 +317,162 @@ int HEU_2opt_grasp_iter(instance *inst) { (void)HEU_Grasp_iter(inst, inst->param
 int HEU_2opt_greedy(instance *inst) { (void)HEU_greedy(inst); return alg_2opt(inst); }
 int HEU_2opt_greedy_iter(instance *inst) { (void)HEU_Greedy_iter(inst); return alg_2opt(inst); }
 
+/* ---- VNS (src/vns.c) ------------------------------------------------------------------------------------- */
+
+/* vns.c:11-100: three random tour positions, segments b..c and d..e swap places, cost recomputed.
+ * The draws and the list surgery are host logic; the cost is one batched fitness on the device.
+ * The reference reads tour[idx3+1] one past its array when idx3 == n-1 (:57): here that index wraps
+ * to the tour's first node (the only value that keeps the successor list a tour). */
+int kick(instance *inst) {
+    const int n = inst->num_nodes;
+    edge *e = inst->solution.edges;
+    int *tour = malloc(sizeof(int) * (size_t)n);
+    for (int k = 0, v = 0; k < n; k++) { tour[k] = v; v = e[v].j; }
+    int p1 = rand_choice(0, n), p2 = p1, p3 = p1;
+    while (p2 == p1 || abs(p1 - p2) <= 1) p2 = rand_choice(0, n);
+    while (p3 == p1 || p3 == p2 || abs(p1 - p3) <= 1 || abs(p2 - p3) <= 1) p3 = rand_choice(0, n);
+    int t;
+    if (p1 > p2) { t = p1; p1 = p2; p2 = t; }
+    if (p1 > p3) { t = p1; p1 = p3; p3 = t; }
+    if (p2 > p3) { t = p2; p2 = p3; p3 = t; }
+    const int a = tour[p1], b = tour[p1 + 1], c = tour[p2], d = tour[p2 + 1], g = tour[p3];
+    const int f = tour[p3 + 1 == n ? 0 : p3 + 1];
+    e[a].j = d; e[g].j = b; e[c].j = f;                      /* :60-62 */
+    for (int k = 0, v = 0; k < n; k++) { tour[k] = v; v = e[v].j; }
+    double cost = 0.0;
+    fitness_batch(inst, tour, 1, &cost);                     /* :77-86, same edge order as fitness() */
+    inst->solution.obj_best = cost;
+    for (int k = 0; k < n; k++) { e[tour[k]].i = tour[k]; e[tour[k]].j = tour[k + 1 == n ? 0 : k + 1]; }
+    free(tour);
+    return 0;
+}
+
+/* vns.c:103-166 */
+int tsp_host_vns(instance *inst, long long max_rounds) {
+    const int n = inst->num_nodes;
+    const int time_limit = inst->params.time_limit > 0 ? inst->params.time_limit : DEFAULT_TIME_LIM;
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    int status = HEU_2opt_greedy_iter(inst);                 /* :116 */
+    double best_obj = inst->solution.obj_best;
+    edge *best = malloc(sizeof(edge) * (size_t)n);
+    memcpy(best, inst->solution.edges, sizeof(edge) * (size_t)n);
+    for (long long round = 0; max_rounds < 0 || round < max_rounds; round++) {
+        gettimeofday(&t1, 0);
+        if (get_elapsed_time(t0, t1) > time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
+        kick(inst);
+        status = alg_2opt(inst);
+        if (inst->solution.obj_best < best_obj) {
+            best_obj = inst->solution.obj_best;
+            memcpy(best, inst->solution.edges, sizeof(edge) * (size_t)n);
+            if (inst->params.verbose >= 3) LOG_I("Updated incumbent: %0.0f", best_obj);
+        }
+        inst->solution.obj_best = best_obj;                  /* :157-158: always restart from the incumbent */
+        memcpy(inst->solution.edges, best, sizeof(edge) * (size_t)n);
+    }
+    inst->solution.obj_best = best_obj;
+    memcpy(inst->solution.edges, best, sizeof(edge) * (size_t)n);
+    free(best);
+    return status;
+}
+
+int HEU_VNS(instance *inst) { return tsp_host_vns(inst, -1); }
+
+/* ---- tabu search (src/tabusearch.c:188-320) ---------------------------------------------------------------- */
+
+/* The stamps stay on the device for the whole search (the reference CALLOCs num_columns ints, :195).
+ * check_tenure's lazy clearing (:83-92) in the kick's `&&` chain (:282-285) is replayed on the host
+ * from one 4-stamp read; the clears it implies are written back. */
+static int kick_edges_free(tsp_dev_tabu *tb, const int idx[4], int iter, int tenure) {
+    int val[4];
+    int rc = tsp_dev_tabu_get(tb, idx, val, 4);
+    if (rc) dev_fail("tsp_dev_tabu_get", rc);
+    int clear_idx[4], zeros[4] = {0, 0, 0, 0}, nclear = 0, is_free = 1;
+    for (int k = 0; k < 4; k++) {
+        if (iter < 0 || tenure < 0 || val[k] == 0) continue;
+        if (iter - val[k] > tenure) { clear_idx[nclear++] = idx[k]; continue; }
+        is_free = 0;                                         /* in the tabu list: the chain stops here */
+        break;
+    }
+    if (nclear) { rc = tsp_dev_tabu_set(tb, clear_idx, zeros, nclear); if (rc) dev_fail("tsp_dev_tabu_set", rc); }
+    return is_free;
+}
+
+int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
+    const int n = inst->num_nodes;
+    edge *e = inst->solution.edges;
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    int status = HEU_2opt_greedy_iter(inst);                 /* :200 */
+    if (status) LOG_E("An error occurred in HEU_2opt_greedy_iter");
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_inst *d = dev_inst_locked(inst);
+    tsp_dev_tabu *tb = NULL;
+    int rc = tsp_dev_tabu_create(d, &tb);
+    pthread_mutex_unlock(&g_lock);
+    if (rc) dev_fail("tsp_dev_tabu_create", rc);
+    int *prev = calloc((size_t)n, sizeof(int));
+    double best_obj = DBL_MAX;
+    edge *best = calloc((size_t)n, sizeof(edge));
+    int lo = (int)ceil(n * 0.02), hi = (int)round(n * 0.1);  /* :213-214, MIN/MAX_TENURE_RATE :12-13 */
+    if (lo == hi) hi += 2; else if (hi < lo) { int t = lo; lo = hi; hi = t; }
+    int tenure = lo, rising = 0;
+    for (int iter = 1; max_iterations < 0 || iter <= max_iterations; iter++) {
+        gettimeofday(&t1, 0);
+        if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
+        tsp_two_opt_stats st;
+        memset(&st, 0, sizeof st);
+        double obj = inst->solution.obj_best;
+        pthread_mutex_lock(&g_lock);
+        rc = tsp_dev_two_opt_tabu(d, tb, iter, tenure, &e[0].j, 2, &obj, prev, limit_of(inst), &st);   /* :238 */
+        pthread_mutex_unlock(&g_lock);
+        if (rc < 0) dev_fail("tsp_dev_two_opt_tabu", rc);
+        inst->solution.obj_best = obj;
+        keep_stats(&st);
+        if (obj < best_obj) { best_obj = obj; memcpy(best, e, sizeof(edge) * (size_t)n); }
+        if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
+        int a, b, a1, b1;
+        for (;;) {                                           /* :262-287 */
+            a = rand_choice(0, n); b = rand_choice(0, n);
+            a1 = e[a].j; b1 = e[b].j;
+            if (a == b || a1 == b || b1 == a) continue;
+            const int idx[4] = {x_udir_pos(a, a1, n), x_udir_pos(b, b1, n), x_udir_pos(a, b, n), x_udir_pos(a1, b1, n)};
+            pthread_mutex_lock(&g_lock);
+            const int ok = kick_edges_free(tb, idx, iter, tenure);
+            pthread_mutex_unlock(&g_lock);
+            if (ok) break;
+        }
+        e[a].j = b; e[a1].j = b1;
+        reverse_path(inst, b, a1, prev);
+        if (policy == 0) {                                   /* step_policy :33-37 */
+            if (iter % 100 == 0) tenure = (tenure == lo) ? hi : lo;
+        } else if (policy == 1) {                            /* linear_policy :47-59 */
+            if (tenure > hi) tenure = hi;
+            if (tenure < lo) tenure = lo;
+            if (tenure == hi || tenure == lo) rising = !rising;
+            if (rising) tenure++; else tenure--;
+        } else {                                             /* random_policy :69-72 */
+            if (iter == 1 || iter % 100 == 0) tenure = rand_choice(lo, hi + 1);
+        }
+        const int sidx[2] = {x_udir_pos(a, a1, n), x_udir_pos(b, b1, n)}, sval[2] = {iter, iter};
+        pthread_mutex_lock(&g_lock);
+        rc = tsp_dev_tabu_set(tb, sidx, sval, 2);            /* :306-309 */
+        pthread_mutex_unlock(&g_lock);
+        if (rc) dev_fail("tsp_dev_tabu_set", rc);
+    }
+    inst->solution.obj_best = best_obj;
+    memcpy(e, best, sizeof(edge) * (size_t)n);
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_tabu_destroy(tb);
+    pthread_mutex_unlock(&g_lock);
+    free(prev); free(best);
+    return status;
+}
+
+int HEU_Tabu_step(instance *inst) { return tsp_host_tabu(inst, 0, -1); }
+int HEU_Tabu_lin(instance *inst) { return tsp_host_tabu(inst, 1, -1); }
+int HEU_Tabu_rand(instance *inst) { return tsp_host_tabu(inst, 2, -1); }
+
 /* genetic.c:51-60 for `count` chromosomes of n nodes each */
 int fitness_batch(instance *inst, const int *chromosomes, int count, double *fitness_out) {
     pthread_mutex_lock(&g_lock);
@@ -392,9 +548,16 @@ int TSP_heuc(instance *inst) {
     case SOLVE_2OPT_GRASP_ITER: HEU_2opt_grasp_iter(inst); break;
     case SOLVE_2OPT_GREEDY: HEU_2opt_greedy(inst); break;
     case SOLVE_2OPT_GREEDY_ITER: HEU_2opt_greedy_iter(inst); break;
+    case SOLVE_VNS: HEU_VNS(inst); break;
+    case SOLVE_TABU_STEP:
+    case SOLVE_TABU_LIN:
+    case SOLVE_TABU_RAND:
+        if (inst->params.time_limit <= 0) LOG_E("TABU_* runs until the time limit: pass -t <seconds> (tabusearch.c:231)");
+        tsp_host_tabu(inst, inst->params.method.id - SOLVE_TABU_STEP, -1);
+        break;
     default:
         LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, GRASP, GRASP_ITER, "
-              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER)",
+              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND)",
               inst->params.method.name ? inst->params.method.name : "?");
     }
     gettimeofday(&t1, 0);

@@ -113,6 +113,13 @@ int HEU_2opt_greedy_iter(instance *inst);                                       
 /* ---- src/tabusearch.c (externally linked there, not in its header) --------------------------- */
 int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int iter, const int tenure); /* :107 */
 
+/* ---- src/tabusearch.c / src/vns.c drivers (wall-clock bounded like the reference's) -------------- */
+int HEU_Tabu_step(instance *inst);                                                       /* tabusearch.c:323 */
+int HEU_Tabu_lin(instance *inst);                                                        /* :328 */
+int HEU_Tabu_rand(instance *inst);                                                       /* :333 */
+int kick(instance *inst);                                                                /* vns.c:11  */
+int HEU_VNS(instance *inst);                                                             /* vns.c:103 */
+
 /* ---- src/genetic.c : fitness of `count` chromosomes at once (the reference scores one at a time, :51) */
 int fitness_batch(instance *inst, const int *chromosomes, int count, double *fitness_out);
 
@@ -130,6 +137,11 @@ void export_tour(instance *inst);
  * inst->solution (ties -> lowest start).  rank/world shard the starts (k % world == rank). */
 int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost,
                               int *best_start);
+/* The two drivers with a cap on the number of rounds / iterations in addition to the time limit
+ * (max < 0 = time limit only, which is what HEU_VNS / HEU_Tabu_* pass).  policy: 0 step, 1 linear,
+ * 2 random.  The reference's loops are bounded by the wall clock alone, which no test can reproduce. */
+int tsp_host_vns(instance *inst, long long max_rounds);
+int tsp_host_tabu(instance *inst, int policy, long long max_iterations);
 /* Counters of the last alg_2opt / alg_2opt_tabu call of this thread. */
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms);
 /* Releases the cached device context / instances (optional; also done at exit). */
