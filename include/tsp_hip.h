@@ -127,6 +127,10 @@ int tsp_dev_selftest_raw_sqrt(tsp_dev_ctx *ctx, const double *in, int count, dou
 int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, const double *urand,
                       int *succ, int succ_stride, int64_t tour_stride, double *obj, int *status_out);
 
+/* HEU_extramileage (src/heuristics.c:208-314): farthest pair, then cheapest insertion of every other
+ * node; writes the successor list and the reference's obj (2*d(A,B) + the sum of the extra mileages). */
+int tsp_dev_extramileage(tsp_dev_inst *inst, int *succ, int succ_stride, double *obj);
+
 /* ---- 2-opt on host-resident tours: replaces alg_2opt / alg_2opt_tabu(skip_edge==NULL) ------ */
 /* B tours in/out.  obj[B] in/out: FIRST adds the applied deltas to the incoming value like
  * `obj_best += delta` (src/heuristics.c:486); BEST overwrites it with the recomputed tour cost

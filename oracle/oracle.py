@@ -55,6 +55,7 @@ def lib():
         L.orc_greedy.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
         L.orc_grasp.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp]
         L.orc_greedy_iter.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
+        L.orc_extramileage.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
         L.orc_two_opt_first.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_double, C.c_int,
                                         C.POINTER(Stats), C.POINTER(Move), C.c_longlong]
         L.orc_two_opt_best.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, ip, C.c_int, C.c_int,
@@ -150,6 +151,15 @@ def greedy_iter(xy, wtype, integer_cost=1):
     succ = np.zeros(n, dtype=np.int32)
     obj = C.c_double(0)
     st = lib().orc_greedy_iter(_d(xy), n, wtype, integer_cost, _i(succ), C.byref(obj))
+    return st, succ, obj.value
+
+
+def extramileage(xy, wtype, integer_cost=1):
+    xy = _xy(xy)
+    n = len(xy)
+    succ = np.zeros(n, dtype=np.int32)
+    obj = C.c_double(0)
+    st = lib().orc_extramileage(_d(xy), n, wtype, integer_cost, _i(succ), C.byref(obj))
     return st, succ, obj.value
 
 

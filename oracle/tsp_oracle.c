@@ -174,6 +174,48 @@ int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *s
     return ORC_OK;
 }
 
+/* src/heuristics.c:208-314 */
+int orc_extramileage(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj) {
+    char *in_tour = calloc((size_t)n, 1);
+    int *from = calloc((size_t)n, sizeof(int)), *to = calloc((size_t)n, sizeof(int));  /* edges in insertion-slot order */
+    memset(succ, 0, sizeof(int) * (size_t)n);
+    int far_a = 0, far_b = 1;
+    double far_d = 0.0;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) {
+            double d = orc_dist(xy, i, j, wtype, integer_cost);
+            if (d > far_d) { far_a = i; far_b = j; far_d = d; }
+        }
+    int m = 0;
+    from[m] = far_a; to[m] = far_b; m++;
+    from[m] = far_b; to[m] = far_a; m++;
+    succ[far_a] = far_b; succ[far_b] = far_a;
+    in_tour[far_a] = in_tour[far_b] = 1;
+    double total = 2 * orc_dist(xy, far_a, far_b, wtype, integer_cost);
+    while (m < n) {
+        double low = DBL_MAX;
+        int pick_node = -1, pick_slot = -1;
+        for (int c = 0; c < n; c++) {
+            if (in_tour[c]) continue;
+            for (int s = 0; s < m; s++) {
+                double extra = orc_dist(xy, from[s], c, wtype, integer_cost) + orc_dist(xy, c, to[s], wtype, integer_cost)
+                             - orc_dist(xy, from[s], to[s], wtype, integer_cost);
+                if (extra < low) { low = extra; pick_node = c; pick_slot = s; }
+            }
+        }
+        if (pick_slot < 0) break;
+        const int a = from[pick_slot], b = to[pick_slot];
+        succ[a] = pick_node; succ[pick_node] = b;
+        to[pick_slot] = pick_node;                 /* the slot now holds (a, c) */
+        from[m] = pick_node; to[m] = b; m++;       /* and (c, b) is appended   */
+        in_tour[pick_node] = 1;
+        total += low;
+    }
+    *obj = total;
+    free(in_tour); free(from); free(to);
+    return ORC_OK;
+}
+
 /* ---- 2-opt ----------------------------------------------------------------------------- */
 
 static void rebuild_prev(int n, const int *succ, int *prev) {

@@ -65,6 +65,9 @@ int orc_grasp(const double *xy, int n, int wtype, int integer_cost, int start, c
 /* src/heuristics.c:168-205 (all n starting nodes, keep the best) */
 int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj);
 
+/* src/heuristics.c:208-314 (farthest pair + cheapest insertion) */
+int orc_extramileage(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj);
+
 /* src/heuristics.c:438-502 (first improvement, moves applied immediately).
  * clock_per_pair != 0 also calls gettimeofday once per pair as the reference does (:456). */
 int orc_two_opt_first(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,

@@ -33,11 +33,10 @@ INST = os.path.join(HERE, "instances")
 
 
 def reference_results():
-    keep = {"constructive_heuristics_new.csv": ["GREEDY", "GREEDY_ITER", "GRASP"],
-            "constructive_heuristics_2opt_new.csv": ["2OPT_GREEDY", "2OPT_GREEDY_ITER"]}
+    keep = {"constructive_heuristics_new.csv": ["GREEDY", "GREEDY_ITER", "EXTR_MILE", "GRASP"],
+            "constructive_heuristics_2opt_new.csv": ["2OPT_GREEDY", "2OPT_GREEDY_ITER", "2OPT_EXTR_MIL"]}
     out = {"_source": "deno750/TSP_Optimization results/*.csv, -seed 123; see make_golden.py",
-           "_dropped": "EXTR_MILE/2OPT_EXTR_MIL (out of scope), 2OPT_GRASP (stale revision, "
-                       "SURVEY.md section 4), *_GRASP_ITER (wall-clock bound)",
+           "_dropped": "2OPT_GRASP (stale revision, SURVEY.md section 4), *_GRASP_ITER (wall-clock bound)",
            "instances": {}}
     for fn, cols in keep.items():
         with open(os.path.join(REF, fn)) as f:

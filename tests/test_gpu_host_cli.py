@@ -255,7 +255,8 @@ def run_cli(args):
     ("att532", "GREEDY", "GREEDY"), ("att532", "2OPT_GREEDY", "2OPT_GREEDY"), ("att532", "GRASP", "GRASP"),
     ("att532", "GREEDY_ITER", "GREEDY_ITER"), ("att532", "2OPT_GREEDY_ITER", "2OPT_GREEDY_ITER"),
     ("lin318", "2OPT_GREEDY", "2OPT_GREEDY"), ("dsj1000", "2OPT_GREEDY", "2OPT_GREEDY"),
-    ("pr1002", "GRASP", "GRASP"),
+    ("pr1002", "GRASP", "GRASP"), ("att532", "EXTR_MILE", "EXTR_MILE"), ("att532", "2OPT_EXTR_MIL", "2OPT_EXTR_MIL"),
+    ("rat783", "2OPT_EXTR_MIL", "2OPT_EXTR_MIL"),
 ])
 def test_cli_perfprof_prints_the_reference_numbers(name, method, key):
     out = run_cli(["-f", os.path.join(INSTANCES, name + ".tsp"), "-method", method, "-seed", "123",

@@ -116,6 +116,34 @@ def test_grasp_matches_oracle_and_reference(eng, ctx, name):
         assert obj[0] == REF[name]["GRASP"]            # -seed 123, start node 0
 
 
+@pytest.mark.parametrize("name", sorted(k for k in REF if k not in ("ali535", "gr431", "gr666")))
+def test_extramileage_equals_reference_csv(eng, ctx, name):
+    """results/constructive_heuristics_new.csv EXTR_MILE and ..._2opt_new.csv 2OPT_EXTR_MIL, on the device."""
+    xy, wt, inst = make_inst(eng, ctx, name)
+    succ, obj = inst.extramileage()
+    assert O.is_tour(succ) and obj == REF[name]["EXTR_MILE"] and obj == O.succ_cost(xy, wt, succ)
+    rc, s2, o2, st = inst.two_opt(succ, obj, mode=eng.FIRST)
+    inst.close()
+    assert o2 == REF[name]["2OPT_EXTR_MIL"]
+
+
+@pytest.mark.parametrize("name,ic", [("berlin52", 1), ("pr299", 1), ("d493", 0), ("att532", 1)])
+def test_extramileage_matches_oracle_tour(eng, ctx, name, ic):
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, ic)
+    succ, obj = inst.extramileage()
+    inst.close()
+    _, es, eo = O.extramileage(xy, wt, ic)
+    assert (succ == es).all() and obj == eo
+
+
+def test_extramileage_geo_within_tolerance(eng, ctx):
+    xy, wt, inst = make_inst(eng, ctx, "gr431")
+    succ, obj = inst.extramileage()
+    inst.close()
+    assert O.is_tour(succ) and abs(obj - REF["gr431"]["EXTR_MILE"]) <= 0.005 * REF["gr431"]["EXTR_MILE"]
+
+
 def test_construct_wrong_starting_node(eng, ctx):
     xy, wt, inst = make_inst(eng, ctx, "berlin52")
     succ, obj, status = inst.construct(eng.GREEDY, np.array([52], dtype=np.int32))

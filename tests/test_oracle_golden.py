@@ -48,6 +48,17 @@ def test_greedy_iter_and_2opt_match_reference_csv(name):
     assert obj2 == REF[name]["2OPT_GREEDY_ITER"]
 
 
+@pytest.mark.parametrize("name", sorted(ITER_OK))
+def test_extramileage_and_2opt_match_reference_csv(name):
+    xy, wt = load_instance(name)
+    st, succ, obj = O.extramileage(xy, wt)
+    assert st == 0 and O.is_tour(succ)
+    assert obj == REF[name]["EXTR_MILE"]                    # results/constructive_heuristics_new.csv
+    assert obj == O.succ_cost(xy, wt, succ)
+    _, s2, o2, _, _ = O.two_opt_first(xy, wt, succ, obj)
+    assert o2 == REF[name]["2OPT_EXTR_MIL"]                 # results/constructive_heuristics_2opt_new.csv
+
+
 @pytest.mark.parametrize("name", ["berlin52", "pr299", "att532", "rand1000"])
 def test_counters_match_survey_appendix_b(name):
     xy, wt = load_instance(name)

@@ -55,6 +55,7 @@ def lib():
         L.tsp_dev_selftest_raw_sqrt.argtypes = [vp, dp, C.c_int, dp]
         L.tsp_dev_dist_matrix.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float)]
         L.tsp_dev_construct.argtypes = [vp, C.c_int, C.c_int, ip, dp, ip, C.c_int, C.c_int64, dp, ip]
+        L.tsp_dev_extramileage.argtypes = [vp, ip, C.c_int, dp]
         L.tsp_dev_two_opt.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, C.c_int, C.c_int64, dp,
                                       C.c_double, sp]
         L.tsp_dev_tabu_create.argtypes = [vp, C.POINTER(vp)]
@@ -82,7 +83,7 @@ def lib():
 EXPORTED = [
     "tsp_dev_open", "tsp_dev_close", "tsp_dev_last_error", "tsp_dev_count", "tsp_dev_synchronize",
     "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size",
-    "tsp_dev_dist_pairs", "tsp_dev_selftest_raw_sqrt", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_two_opt",
+    "tsp_dev_dist_pairs", "tsp_dev_selftest_raw_sqrt", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_extramileage", "tsp_dev_two_opt",
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
@@ -193,6 +194,13 @@ class Instance:
         _check(lib().tsp_dev_construct(self._h, kind, B, _i(starts), up, _i(succ), 1, n, _d(obj), _i(status)),
                allow=(OK, WRONG_STARTING_NODE))
         return succ, obj, status
+
+    def extramileage(self):
+        """HEU_extramileage -> (succ [n] int32, obj)"""
+        succ = np.zeros(self.n, dtype=np.int32)
+        obj = C.c_double(0)
+        _check(lib().tsp_dev_extramileage(self._h, _i(succ), 1, C.byref(obj)))
+        return succ, obj.value
 
     # -- alg_2opt / alg_2opt_tabu(NULL) ---------------------------------------------------
     def two_opt(self, succ, obj, mode=FIRST, engine=ENGINE_AUTO, time_limit=-1.0):

@@ -264,6 +264,18 @@ int HEU_Grasp_iter(instance *inst, int time_lim) {
     return TIME_LIMIT_EXCEEDED; /* the reference only ever leaves this loop through the time limit (:522-524) */
 }
 
+/* :208-314 -- farthest pair + n-2 cheapest insertions, one scan/apply launch pair per inserted node */
+int HEU_extramileage(instance *inst) {
+    double obj = 0.0;
+    pthread_mutex_lock(&g_lock);
+    int rc = tsp_dev_extramileage(dev_inst_locked(inst), &inst->solution.edges[0].j, 2, &obj);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("tsp_dev_extramileage", rc);
+    stamp_edge_sources(inst);
+    inst->solution.obj_best = obj;
+    return 0;
+}
+
 /* ---- refinement ------------------------------------------------------------------------------------------ */
 
 /* src/heuristics.c:438-502 */
@@ -316,6 +328,7 @@ int HEU_2opt_grasp(instance *inst) { (void)HEU_Grasp(inst); return alg_2opt(inst
 int HEU_2opt_grasp_iter(instance *inst) { (void)HEU_Grasp_iter(inst, inst->params.time_limit / 5); return alg_2opt(inst); }
 int HEU_2opt_greedy(instance *inst) { (void)HEU_greedy(inst); return alg_2opt(inst); }
 int HEU_2opt_greedy_iter(instance *inst) { (void)HEU_Greedy_iter(inst); return alg_2opt(inst); }
+int HEU_2opt_extramileage(instance *inst) { (void)HEU_extramileage(inst); return alg_2opt(inst); }
 
 /* ---- VNS (src/vns.c) ------------------------------------------------------------------------------------- */
 
@@ -548,6 +561,8 @@ int TSP_heuc(instance *inst) {
     case SOLVE_2OPT_GRASP_ITER: HEU_2opt_grasp_iter(inst); break;
     case SOLVE_2OPT_GREEDY: HEU_2opt_greedy(inst); break;
     case SOLVE_2OPT_GREEDY_ITER: HEU_2opt_greedy_iter(inst); break;
+    case SOLVE_EXTR_MIL: HEU_extramileage(inst); break;
+    case SOLVE_2OPT_EXTR_MIL: HEU_2opt_extramileage(inst); break;
     case SOLVE_VNS: HEU_VNS(inst); break;
     case SOLVE_TABU_STEP:
     case SOLVE_TABU_LIN:
@@ -556,7 +571,7 @@ int TSP_heuc(instance *inst) {
         tsp_host_tabu(inst, inst->params.method.id - SOLVE_TABU_STEP, -1);
         break;
     default:
-        LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, GRASP, GRASP_ITER, "
+        LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, EXTR_MILE, GRASP, GRASP_ITER, 2OPT_EXTR_MIL, "
               "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND)",
               inst->params.method.name ? inst->params.method.name : "?");
     }

@@ -102,6 +102,7 @@ int greedy(instance *inst, int starting_node);                                  
 int grasp(instance *inst, int starting_node);                                            /* :82  */
 int HEU_greedy(instance *inst);                                                          /* :160 */
 int HEU_Greedy_iter(instance *inst);                                                     /* :168 */
+int HEU_extramileage(instance *inst);                                                    /* :208 */
 int alg_2opt(instance *inst);                                                            /* :438 */
 int HEU_Grasp(instance *inst);                                                           /* :505 */
 int HEU_Grasp_iter(instance *inst, int time_lim);                                        /* :510 */
@@ -109,6 +110,7 @@ int HEU_2opt_grasp(instance *inst);                                             
 int HEU_2opt_grasp_iter(instance *inst);                                                 /* :559 */
 int HEU_2opt_greedy(instance *inst);                                                     /* :572 */
 int HEU_2opt_greedy_iter(instance *inst);                                                /* :584 */
+int HEU_2opt_extramileage(instance *inst);                                               /* :596 */
 
 /* ---- src/tabusearch.c (externally linked there, not in its header) --------------------------- */
 int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int iter, const int tenure); /* :107 */
