@@ -74,6 +74,7 @@ def lib():
         L.orc_vns.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong, C.POINTER(C.c_longlong)]
         L.orc_tabu.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong,
                                C.POINTER(C.c_longlong)]
+        L.orc_genetic.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_longlong, ip, dp]
         L.orc_srandom.argtypes = [C.c_uint]
         L.orc_urand.restype = C.c_double
         L.orc_parse_tsplib.argtypes = [C.c_char_p, dp, C.c_int, ip]
@@ -229,6 +230,15 @@ def tabu(xy, wtype, succ, obj, iterations, policy=0, integer_cost=1):
     mv = C.c_longlong(0)
     lib().orc_tabu(_d(xy), len(xy), wtype, integer_cost, policy, _i(succ), C.byref(o), iterations, C.byref(mv))
     return succ, o.value, mv.value
+
+
+def genetic(xy, wtype, generations, integer_cost=1):
+    """-> (incumbent succ, incumbent cost) after `generations` generations (draws from libc random())"""
+    xy = _xy(xy)
+    succ = np.zeros(len(xy), dtype=np.int32)
+    o = C.c_double(0)
+    lib().orc_genetic(_d(xy), len(xy), wtype, integer_cost, generations, _i(succ), C.byref(o))
+    return succ, o.value
 
 
 def perm_cost(xy, wtype, perm, integer_cost=1):

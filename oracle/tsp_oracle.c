@@ -454,6 +454,144 @@ int orc_tabu(const double *xy, int n, int wtype, int integer_cost, int policy, i
     return ORC_OK;
 }
 
+
+/* ---- genetic algorithm (src/genetic.c) --------------------------------------------------------------------- */
+#define GA_POPULATION 1000      /* genetic.c:12 */
+#define GA_MUTATION_RATE 0.1    /* :13 */
+#define GA_PARENT_RATE 0.6      /* :14 */
+#define GA_HEURISTIC_INIT 0.0   /* :16 */
+#define GA_CROSSOVER_SPLIT 0.0  /* :17 */
+#define GA_TWO_OPT_MUT 0.00     /* :18 */
+
+typedef struct { int *genes; double fit; } ga_member;   /* genetic.c:22-25 */
+
+/* :62-68 -- the difference of two doubles returned as int: ties and sub-unit gaps compare equal */
+static int ga_by_fitness_desc(const void *l, const void *r) {
+    return (int)(((const ga_member *)r)->fit - ((const ga_member *)l)->fit);
+}
+
+/* rank roulette of :96-128 / :309-326: slot = floor((-1 + sqrt(1 + 8 u)) / 2), then the next free slot upwards */
+static int ga_roulette_pick(double rank_sum, char *taken, int count_slots) {
+    const double u = rand_in(1, rank_sum);
+    int slot = (int)((-1 + sqrt(1 + 8 * u)) / 2.0);
+    while (slot < count_slots - 1 && taken[slot]) slot++;
+    if (taken[slot]) return -1;
+    taken[slot] = 1;
+    return slot;
+}
+
+/* :78-131 */
+static void ga_select_parents(ga_member *pop, int *parents, int want, int pop_size) {
+    char *taken = calloc((size_t)pop_size, 1);
+    qsort(pop, (size_t)pop_size, sizeof(ga_member), ga_by_fitness_desc);
+    const double rank_sum = pop_size * (pop_size + 1) / 2;
+    for (int got = 0; got < want;) {
+        const int s = ga_roulette_pick(rank_sum, taken, pop_size);
+        if (s >= 0) parents[got++] = s;
+    }
+    free(taken);
+}
+
+/* :143-229 */
+static void ga_crossover(int n, const int *p1, const int *p2, int *child, char *seen) {
+    memset(seen, 0, (size_t)n);
+    const double u = orc_urand();
+    if (u < GA_CROSSOVER_SPLIT) {                       /* method 1, :150-175 */
+        const int cut = rand_in(0, n);
+        int w = 0;
+        for (int k = 0; k < n; k++) {
+            if (k <= cut) { seen[p1[k]] = 1; child[w] = p1[k]; }
+            else { if (seen[p2[k]]) continue; child[w] = p2[k]; }
+            w++;
+        }
+        if (w < n) for (int k = 0; k <= cut; k++) { if (seen[p2[k]]) continue; child[w++] = p2[k]; }
+        return;
+    }
+    int lo = rand_in(0, n), hi = rand_in(0, n);  /* method 2, :176-226 */
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+    if (lo == hi) { if (lo > 0) lo -= 1; else hi += 1; }
+    int placed = 0;
+    for (int k = lo; k <= hi; k++) { seen[p1[k]] = 1; child[k] = p1[k]; placed++; }
+    for (int src = hi + 1, dst = hi + 1; placed < n; src++) {
+        const int g = p2[src % n];
+        if (!seen[g]) { child[dst % n] = g; placed++; dst++; }
+    }
+}
+
+/* :375-446 without its 2-opt branch (handled by the caller); returns 1 if that branch was drawn */
+static int ga_mutate_one(int n, int *genes) {
+    const double u = orc_urand();
+    if (!(u < GA_MUTATION_RATE)) return 0;
+    const double method = orc_urand();
+    if (!(method > GA_TWO_OPT_MUT)) return 1;
+    int lo = rand_in(0, n - 1), hi = rand_in(0, n - 1);
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+    if (lo == hi) { if (lo > 0) lo -= 1; else hi += 1; }
+    for (int k = 0, a = lo, b = hi; k < (hi - lo) / 2; k++, a++, b--) { const int t = genes[a]; genes[a] = genes[b]; genes[b] = t; }
+    return 0;
+}
+
+/* :266-331 -- including the reference's aliasing: `total` holds shallow copies, so a population slot that
+ * was already overwritten can be copied again later with its old fitness */
+static void ga_choose_survivors(int n, ga_member *pop, int pop_size, const ga_member *kids, int kid_count) {
+    const int total_n = pop_size + kid_count;
+    ga_member *total = calloc((size_t)total_n, sizeof(ga_member));
+    char *taken = calloc((size_t)total_n, 1);
+    int w = 0;
+    for (int k = 0; k < kid_count; k++) total[w++] = kids[k];
+    for (int k = 0; k < pop_size; k++) total[w++] = pop[k];
+    qsort(total, (size_t)total_n, sizeof(ga_member), ga_by_fitness_desc);
+    const double rank_sum = total_n * (total_n + 1) / 2;
+    for (int got = 0; got < pop_size;) {
+        const int s = ga_roulette_pick(rank_sum, taken, total_n);
+        if (s < 0) continue;
+        memmove(pop[got].genes, total[s].genes, sizeof(int) * (size_t)n);
+        pop[got].fit = total[s].fit;
+        got++;
+    }
+    free(total); free(taken);
+}
+
+/* src/genetic.c:448-565 with a cap on the number of generations instead of the wall clock */
+int orc_genetic(const double *xy, int n, int wtype, int integer_cost, long long generations, int *succ, double *obj) {
+    const int pop_size = GA_POPULATION, parent_count = (int)(pop_size * GA_PARENT_RATE), kid_count = parent_count;
+    ga_member *pop = calloc((size_t)pop_size, sizeof(ga_member)), *kids = calloc((size_t)kid_count, sizeof(ga_member));
+    for (int k = 0; k < pop_size; k++) {
+        pop[k].genes = calloc((size_t)n, sizeof(int));
+        (void)orc_urand();                                   /* :463, HEURISTIC_INIT_RATE is 0 */
+        orc_random_perm(n, pop[k].genes);
+        pop[k].fit = orc_perm_cost(xy, n, wtype, integer_cost, pop[k].genes);
+    }
+    for (int k = 0; k < kid_count; k++) kids[k].genes = calloc((size_t)n, sizeof(int));
+    int *parents = calloc((size_t)parent_count, sizeof(int));
+    char *seen = malloc((size_t)n);
+    double incumbent = DBL_MAX;
+    for (long long gen = 0; gen < generations; gen++) {
+        double best = DBL_MAX; int best_k = 0;
+        for (int k = 0; k < pop_size; k++) if (pop[k].fit < best) { best = pop[k].fit; best_k = k; }
+        if (best < incumbent) { incumbent = best; *obj = best; orc_perm_to_succ(n, pop[best_k].genes, succ); }
+        ga_select_parents(pop, parents, parent_count, pop_size);
+        for (int k = 0; k < parent_count; k++) {
+            ga_crossover(n, pop[parents[k]].genes, pop[parents[(k + 1) % parent_count]].genes, kids[k].genes, seen);
+            kids[k].fit = orc_perm_cost(xy, n, wtype, integer_cost, kids[k].genes);
+        }
+        for (int k = 0; k < kid_count; k++)
+            if (ga_mutate_one(n, kids[k].genes)) {           /* :426-443 */
+                int *s2 = malloc(sizeof(int) * (size_t)n);
+                double o2 = *obj;
+                orc_perm_to_succ(n, kids[k].genes, s2);
+                orc_two_opt_first(xy, n, wtype, integer_cost, s2, &o2, 2.0, 1, NULL, NULL, 0);
+                orc_succ_to_perm(n, s2, kids[k].genes);
+                free(s2);
+            }
+        ga_choose_survivors(n, pop, pop_size, kids, kid_count);
+    }
+    for (int k = 0; k < pop_size; k++) free(pop[k].genes);
+    for (int k = 0; k < kid_count; k++) free(kids[k].genes);
+    free(pop); free(kids); free(parents); free(seen);
+    return ORC_OK;
+}
+
 /* ---- tour cost / representation -------------------------------------------------------- */
 
 /* src/genetic.c:51-60 */

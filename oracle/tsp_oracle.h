@@ -112,6 +112,11 @@ int orc_vns(const double *xy, int n, int wtype, int integer_cost, int *succ, dou
 int orc_tabu(const double *xy, int n, int wtype, int integer_cost, int policy, int *succ, double *obj,
              long long iterations, long long *total_moves);
 
+/* src/genetic.c:448-565 (population 1000, rank-roulette selection, OX-like crossover, reversal mutation,
+ * rank-roulette survivors incl. the reference's chromosome aliasing) with a generation cap; the incumbent
+ * tour / cost are written whenever a generation's best improves on them (:518-526). */
+int orc_genetic(const double *xy, int n, int wtype, int integer_cost, long long generations, int *succ, double *obj);
+
 /* libc RNG access so that tests can reproduce the reference's stream (src/solver.c:264-266) */
 void orc_srandom(unsigned seed);
 double orc_urand(void);

@@ -486,6 +486,170 @@ int HEU_Tabu_step(instance *inst) { return tsp_host_tabu(inst, 0, -1); }
 int HEU_Tabu_lin(instance *inst) { return tsp_host_tabu(inst, 1, -1); }
 int HEU_Tabu_rand(instance *inst) { return tsp_host_tabu(inst, 2, -1); }
 
+
+/* ---- genetic algorithm (src/genetic.c) --------------------------------------------------------------------- */
+#define GA_POPULATION 1000      /* genetic.c:12 */
+#define GA_MUTATION_RATE 0.1    /* :13 */
+#define GA_PARENT_RATE 0.6      /* :14 */
+#define GA_HEURISTIC_INIT 0.0   /* :16 */
+#define GA_CROSSOVER_SPLIT 0.0  /* :17 */
+#define GA_TWO_OPT_MUT 0.00     /* :18 */
+
+typedef struct { int *genes; double fit; } ga_member;   /* genetic.c:22-25 */
+
+/* :62-68 -- the difference of two doubles returned as int: ties and sub-unit gaps compare equal */
+static int ga_by_fitness_desc(const void *l, const void *r) {
+    return (int)(((const ga_member *)r)->fit - ((const ga_member *)l)->fit);
+}
+
+/* rank roulette of :96-128 / :309-326: slot = floor((-1 + sqrt(1 + 8 u)) / 2), then the next free slot upwards */
+static int ga_roulette_pick(double rank_sum, char *taken, int count_slots) {
+    const double u = rand_choice(1, rank_sum);
+    int slot = (int)((-1 + sqrt(1 + 8 * u)) / 2.0);
+    while (slot < count_slots - 1 && taken[slot]) slot++;
+    if (taken[slot]) return -1;
+    taken[slot] = 1;
+    return slot;
+}
+
+/* :78-131 */
+static void ga_select_parents(ga_member *pop, int *parents, int want, int pop_size) {
+    char *taken = calloc((size_t)pop_size, 1);
+    qsort(pop, (size_t)pop_size, sizeof(ga_member), ga_by_fitness_desc);
+    const double rank_sum = pop_size * (pop_size + 1) / 2;
+    for (int got = 0; got < want;) {
+        const int s = ga_roulette_pick(rank_sum, taken, pop_size);
+        if (s >= 0) parents[got++] = s;
+    }
+    free(taken);
+}
+
+/* :143-229 */
+static void ga_crossover(int n, const int *p1, const int *p2, int *child, char *seen) {
+    memset(seen, 0, (size_t)n);
+    const double u = URAND();
+    if (u < GA_CROSSOVER_SPLIT) {                       /* method 1, :150-175 */
+        const int cut = rand_choice(0, n);
+        int w = 0;
+        for (int k = 0; k < n; k++) {
+            if (k <= cut) { seen[p1[k]] = 1; child[w] = p1[k]; }
+            else { if (seen[p2[k]]) continue; child[w] = p2[k]; }
+            w++;
+        }
+        if (w < n) for (int k = 0; k <= cut; k++) { if (seen[p2[k]]) continue; child[w++] = p2[k]; }
+        return;
+    }
+    int lo = rand_choice(0, n), hi = rand_choice(0, n);  /* method 2, :176-226 */
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+    if (lo == hi) { if (lo > 0) lo -= 1; else hi += 1; }
+    int placed = 0;
+    for (int k = lo; k <= hi; k++) { seen[p1[k]] = 1; child[k] = p1[k]; placed++; }
+    for (int src = hi + 1, dst = hi + 1; placed < n; src++) {
+        const int g = p2[src % n];
+        if (!seen[g]) { child[dst % n] = g; placed++; dst++; }
+    }
+}
+
+/* :375-446 without its 2-opt branch (handled by the caller); returns 1 if that branch was drawn */
+static int ga_mutate_one(int n, int *genes) {
+    const double u = URAND();
+    if (!(u < GA_MUTATION_RATE)) return 0;
+    const double method = URAND();
+    if (!(method > GA_TWO_OPT_MUT)) return 1;
+    int lo = rand_choice(0, n - 1), hi = rand_choice(0, n - 1);
+    if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+    if (lo == hi) { if (lo > 0) lo -= 1; else hi += 1; }
+    for (int k = 0, a = lo, b = hi; k < (hi - lo) / 2; k++, a++, b--) { const int t = genes[a]; genes[a] = genes[b]; genes[b] = t; }
+    return 0;
+}
+
+/* :266-331 -- including the reference's aliasing: `total` holds shallow copies, so a population slot that
+ * was already overwritten can be copied again later with its old fitness */
+static void ga_choose_survivors(int n, ga_member *pop, int pop_size, const ga_member *kids, int kid_count) {
+    const int total_n = pop_size + kid_count;
+    ga_member *total = calloc((size_t)total_n, sizeof(ga_member));
+    char *taken = calloc((size_t)total_n, 1);
+    int w = 0;
+    for (int k = 0; k < kid_count; k++) total[w++] = kids[k];
+    for (int k = 0; k < pop_size; k++) total[w++] = pop[k];
+    qsort(total, (size_t)total_n, sizeof(ga_member), ga_by_fitness_desc);
+    const double rank_sum = total_n * (total_n + 1) / 2;
+    for (int got = 0; got < pop_size;) {
+        const int s = ga_roulette_pick(rank_sum, taken, total_n);
+        if (s < 0) continue;
+        memmove(pop[got].genes, total[s].genes, sizeof(int) * (size_t)n);
+        pop[got].fit = total[s].fit;
+        got++;
+    }
+    free(total); free(taken);
+}
+
+/* :448-565 with a cap on the number of generations in addition to the time limit */
+int tsp_host_genetic(instance *inst, long long max_generations) {
+    const int n = inst->num_nodes;
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    const int pop_size = GA_POPULATION, parent_count = (int)(pop_size * GA_PARENT_RATE), kid_count = parent_count;
+    int *pop_slab = calloc((size_t)pop_size * n, sizeof(int)), *kid_slab = calloc((size_t)kid_count * n, sizeof(int));
+    ga_member *pop = calloc((size_t)pop_size, sizeof(ga_member)), *kids = calloc((size_t)kid_count, sizeof(ga_member));
+    double *fit = malloc(sizeof(double) * (size_t)pop_size);
+    for (int k = 0; k < pop_size; k++) {
+        pop[k].genes = pop_slab + (size_t)k * n;
+        const double u = URAND();                            /* :463 */
+        if (u < GA_HEURISTIC_INIT) {
+            const int start = rand_choice(0, n);
+            grasp(inst, start);
+            for (int q = 0, v = start; q < n; q++) { pop[k].genes[q] = v; v = inst->solution.edges[v].j; }
+        } else {                                             /* random_generation :349-364 */
+            for (int q = 0; q < n; q++) pop[k].genes[q] = q;
+            for (int q = 0; q < n; q++) {
+                const int a = rand_choice(0, n), b = rand_choice(0, n);
+                const int t = pop[k].genes[a]; pop[k].genes[a] = pop[k].genes[b]; pop[k].genes[b] = t;
+            }
+        }
+    }
+    fitness_batch(inst, pop_slab, pop_size, fit);            /* :481, whole population in one launch */
+    for (int k = 0; k < pop_size; k++) pop[k].fit = fit[k];
+    for (int k = 0; k < kid_count; k++) kids[k].genes = kid_slab + (size_t)k * n;
+    const int time_limit = inst->params.time_limit > 0 ? inst->params.time_limit : DEFAULT_TIME_LIM;
+    int *parents = calloc((size_t)parent_count, sizeof(int));
+    char *seen = malloc((size_t)n);
+    double incumbent = DBL_MAX;
+    int status = 0;
+    for (long long gen = 0; max_generations < 0 || gen < max_generations; gen++) {
+        gettimeofday(&t1, 0);
+        if (get_elapsed_time(t0, t1) > time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
+        double best = DBL_MAX; int best_k = 0;               /* fitness_metrics :333-347 */
+        for (int k = 0; k < pop_size; k++) if (pop[k].fit < best) { best = pop[k].fit; best_k = k; }
+        if (best < incumbent) {                              /* :518-526, from_chromosome_to_edges :33-42 */
+            incumbent = best;
+            inst->solution.obj_best = best;
+            const int *g = pop[best_k].genes;
+            for (int q = 0; q < n; q++) { inst->solution.edges[g[q]].i = g[q]; inst->solution.edges[g[q]].j = g[q + 1 == n ? 0 : q + 1]; }
+        }
+        ga_select_parents(pop, parents, parent_count, pop_size);
+        for (int k = 0; k < parent_count; k++)               /* procreate :240-256 */
+            ga_crossover(n, pop[parents[k]].genes, pop[parents[(k + 1) % parent_count]].genes, kids[k].genes, seen);
+        fitness_batch(inst, kid_slab, kid_count, fit);       /* :251, all offspring in one launch (no draws in between) */
+        for (int k = 0; k < kid_count; k++) kids[k].fit = fit[k];
+        for (int k = 0; k < kid_count; k++)
+            if (ga_mutate_one(n, kids[k].genes)) {           /* mutation method 3, :426-443: alg_2opt on a private copy */
+                instance tmp;
+                copy_instance(&tmp, inst);
+                for (int q = 0; q < n; q++) { tmp.solution.edges[kids[k].genes[q]].i = kids[k].genes[q]; tmp.solution.edges[kids[k].genes[q]].j = kids[k].genes[q + 1 == n ? 0 : q + 1]; }
+                tmp.params.time_limit = 2;
+                alg_2opt(&tmp);
+                for (int q = 0, v = 0; q < n; q++) { kids[k].genes[q] = tmp.solution.edges[v].i; v = tmp.solution.edges[v].j; }
+                free_instance(&tmp);
+            }
+        ga_choose_survivors(n, pop, pop_size, kids, kid_count);
+    }
+    free(pop_slab); free(kid_slab); free(pop); free(kids); free(fit); free(parents); free(seen);
+    return status;
+}
+
+int HEU_Genetic(instance *inst) { return tsp_host_genetic(inst, -1); }
+
 /* genetic.c:51-60 for `count` chromosomes of n nodes each */
 int fitness_batch(instance *inst, const int *chromosomes, int count, double *fitness_out) {
     pthread_mutex_lock(&g_lock);
@@ -564,6 +728,7 @@ int TSP_heuc(instance *inst) {
     case SOLVE_EXTR_MIL: HEU_extramileage(inst); break;
     case SOLVE_2OPT_EXTR_MIL: HEU_2opt_extramileage(inst); break;
     case SOLVE_VNS: HEU_VNS(inst); break;
+    case SOLVE_GENETIC: HEU_Genetic(inst); break;
     case SOLVE_TABU_STEP:
     case SOLVE_TABU_LIN:
     case SOLVE_TABU_RAND:
@@ -572,7 +737,7 @@ int TSP_heuc(instance *inst) {
         break;
     default:
         LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, EXTR_MILE, GRASP, GRASP_ITER, 2OPT_EXTR_MIL, "
-              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND)",
+              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND, GENETIC)",
               inst->params.method.name ? inst->params.method.name : "?");
     }
     gettimeofday(&t1, 0);

@@ -121,6 +121,7 @@ int HEU_Tabu_lin(instance *inst);                                               
 int HEU_Tabu_rand(instance *inst);                                                       /* :333 */
 int kick(instance *inst);                                                                /* vns.c:11  */
 int HEU_VNS(instance *inst);                                                             /* vns.c:103 */
+int HEU_Genetic(instance *inst);                                                         /* genetic.c:448 */
 
 /* ---- src/genetic.c : fitness of `count` chromosomes at once (the reference scores one at a time, :51) */
 int fitness_batch(instance *inst, const int *chromosomes, int count, double *fitness_out);
@@ -144,6 +145,7 @@ int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, d
  * 2 random.  The reference's loops are bounded by the wall clock alone, which no test can reproduce. */
 int tsp_host_vns(instance *inst, long long max_rounds);
 int tsp_host_tabu(instance *inst, int policy, long long max_iterations);
+int tsp_host_genetic(instance *inst, long long max_generations);
 /* Counters of the last alg_2opt / alg_2opt_tabu call of this thread. */
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms);
 /* Releases the cached device context / instances (optional; also done at exit). */
