@@ -48,7 +48,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
     dist = None
-    if world > 1:
+    # TSP_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to test it on a 1-GPU box)
+    if world > 1 or os.environ.get("TSP_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
