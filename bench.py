@@ -164,10 +164,12 @@ def main():
             "note": "achieved = evals/launch x 72 B (operands the reference touches per delta evaluation) / "
                     "kernel time; the tiled sweep re-uses operands on chip, so real HBM traffic (traffic) is "
                     "far below it and frac can exceed 1: the kernel is fp64-VALU bound, see DESIGN.md",
-            "valu": {"fp64_instr_per_eval": 40, "achieved_tera_instr_per_s": evals_per_launch * 40 / (ms * 1e-3) / 1e12,
-                     "peak_tera_instr_per_s": 39.3,
-                     "note": "40 fp64-rate VALU instructions per evaluation in the integer-coordinate variant "
-                             "(k_step<6,...>); peak = 78.6 TFLOP/s vector fp64 / 2 (an FMA counts as 2 flops)"},
+            "valu": {"issue_cycles_per_eval": 92, "simd_cycles_per_s_needed": evals_per_launch * 92 / 64 / (ms * 1e-3),
+                     "simd_cycles_per_s_available": 1024 * 2.4e9,
+                     "frac": evals_per_launch * 92 / 64 / (ms * 1e-3) / (1024 * 2.4e9),
+                     "note": "common path of one evaluation in k_step<6,...> = 15 fp64 VALU instructions (4 cycles per "
+                             "wave64 each) + 2 v_sqrt_f64 (16 cycles each, measured by tools/ubench/ops.hip) = 92 issue "
+                             "cycles per wave of 64 evaluations; 1024 SIMDs at the 2.4 GHz nominal clock"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -468,3 +468,24 @@ def test_population_refinement_config5_spot_parity(eng, ctx):
         assert (st[k]["sweeps"], st[k]["evals"], st[k]["moves"]) == (est["sweeps"], est["evals"], est["moves"])
     for k in range(6):
         assert O.is_tour(s2[k]) and o2[k] == O.succ_cost(xy, wt, s2[k])
+
+
+def test_root_filter_on_and_off_give_identical_descents(eng, ctx, monkeypatch):
+    """The raw-root lower bound only skips pairs that cannot change a decision: same tours, costs and
+    counters with TSP_NO_FILTER=1 (every pair evaluated exactly), for both rules, both engines, integer
+    and float costs, general and integer-coordinate variants."""
+    cases = [("rand1500i", rand_instance(1500, seed=5), O.EUC_2D, 1), ("d493", load_instance("d493")[0], O.EUC_2D, 0),
+             ("d493i", load_instance("d493")[0], O.EUC_2D, 1), ("att532", load_instance("att532")[0], O.ATT, 1),
+             ("dsj1000", load_instance("dsj1000")[0], O.CEIL_2D, 1)]
+    for name, xy, wt, ic in cases:
+        _, succ0, obj0 = O.greedy(xy, wt, integer_cost=ic)
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("TSP_NO_FILTER", flag)
+            inst = eng.Instance(ctx, xy, wt, ic)
+            out[flag] = [inst.two_opt(succ0, obj0, mode=m, engine=e) for m in (eng.FIRST, eng.BEST) for e in (1, 2)
+                         if not (m == eng.BEST and e == 2 and len(xy) > 600)]
+            inst.close()
+        for a, b in zip(out["1"], out["0"]):
+            assert (a[1] == b[1]).all() and a[2] == b[2], name
+            assert (a[3]["sweeps"], a[3]["evals"], a[3]["moves"]) == (b[3]["sweeps"], b[3]["evals"], b[3]["moves"]), name

@@ -152,6 +152,16 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
             lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy;
         }
         const double span = sqrt((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
+        {   // root filter margin: two raw roots (each within r * 2^-23 of r <= span, taken at 2^-22 for slack)
+            // + the rounding the exact metric adds to each of the two distances (nint 0.5, ceil/ATT < 1)
+            const char *nof = getenv("TSP_NO_FILTER");
+            const bool sqrt_metric = inst->wtype == TSP_EUC_2D || inst->wtype == TSP_CEIL_2D || inst->wtype == TSP_ATT;
+            inst->filter_margin = 1e300;   // "off": no pair is ever skipped
+            if (sqrt_metric && !(nof && *nof == '1') && span < 1e100) {
+                const double rounding = (inst->integer_cost || inst->wtype == TSP_CEIL_2D) ? 2.0 : 0.0;
+                inst->filter_margin = 2.0 * span * 0x1p-22 + rounding + 1e-6 + span * 0x1p-40;
+            }
+        }
         const char *off = getenv("TSP_NO_ICOORD");
         if (all_int && span < TSP_ICOORD_MAX_DIST && !(off && *off == '1')) {
             if (inst->wtype == TSP_EUC_2D && inst->integer_cost) inst->wtype = tsp::WT_EUC_2D_ICOORD;

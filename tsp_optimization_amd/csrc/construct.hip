@@ -120,6 +120,136 @@ __global__ __launch_bounds__(kConsThreads) void k_construct(const double2 *__res
     if (tid == 0) { obj[b] = total; status[b] = TSP_OK; }
 }
 
+// LDS-resident variant (n <= 16384, 16 n bytes of LDS): four waves, one per SIMD, so the per-step
+// reduction work is not multiplied by sixteen co-resident waves fighting for the same issue slots (that,
+// not memory, bounds k_construct: ~2.5 us per step at any n).  Thread t owns the candidates t + 256 m and
+// keeps their "unvisited" flags in a 64-bit mask; coordinates sit in LDS.  One barrier per arg-min: each
+// wave reduces (d, k) with shuffles, the lane holding the wave's winner writes (d, k, x, y) into the wave's
+// slot of a rotating LDS table, and after the barrier every thread scans the four slots, so the picked
+// node's coordinates arrive with the result.  Same arg-min and tie-break as k_construct.
+constexpr int kConsLdsThreads = 256;
+constexpr int kConsLdsMaxN = 64 * kConsLdsThreads;
+struct alignas(16) ConsSlot { double d, x, y; int k; int pad; };
+
+__device__ __forceinline__ ConsSlot cons_argmin(ArgMin mine, double mx, double my, ConsSlot *table) {
+    ArgMin w = mine;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ArgMin o;
+        o.d = __shfl_xor(w.d, off);
+        o.k = __shfl_xor(w.k, off);
+        if (lt(o, w)) w = o;
+    }
+    const int tid = threadIdx.x;
+    if (mine.k == w.k && (w.k != 0x7fffffff || (tid & 63) == 0)) {  // the winner's lane (lane 0 if the wave has none)
+        ConsSlot sl;
+        sl.d = w.d; sl.k = w.k; sl.x = mx; sl.y = my; sl.pad = 0;
+        table[tid >> 6] = sl;
+    }
+    __syncthreads();
+    ConsSlot r = table[0];
+#pragma unroll
+    for (int q = 1; q < kConsLdsThreads / 64; ++q) {
+        const ConsSlot o = table[q];
+        if (o.d < r.d || (o.d == r.d && o.k < r.k)) r = o;
+    }
+    return r;
+}
+
+template <int WT, bool INT, bool IS_GRASP>
+__global__ __launch_bounds__(kConsLdsThreads) void k_construct_lds(const double2 *__restrict__ coord, int n,
+                                                                  const int *__restrict__ starts,
+                                                                  const double *__restrict__ urand,
+                                                                  int *__restrict__ succ_all, double *__restrict__ obj,
+                                                                  int *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) char cons_smem[];
+    ConsSlot *s_tab = reinterpret_cast<ConsSlot *>(cons_smem);                          // 4 tables x 4 slots
+    double2 *s_xy = reinterpret_cast<double2 *>(cons_smem + 4 * (kConsLdsThreads / 64) * sizeof(ConsSlot));
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int start = starts[b];
+    if (start < 0 || start >= n) {
+        if (tid == 0) { status[b] = TSP_WRONG_STARTING_NODE; obj[b] = 0.0; }
+        return;
+    }
+    int *succ = succ_all + (size_t)b * n;
+    const double *u = IS_GRASP ? urand + (size_t)b * n : nullptr;
+    const int M = (n + kConsLdsThreads - 1) / kConsLdsThreads;
+
+    unsigned long long alive = 0;
+    for (int m = 0; m < M; ++m) {
+        const int k = tid + m * kConsLdsThreads;
+        if (k < n) { s_xy[k] = coord[k]; if (k != start) alive |= 1ull << m; }
+    }
+    const double2 c_start = coord[start];
+    double curx = c_start.x, cury = c_start.y;
+    __syncthreads();
+
+    double total = 0.0;
+    int cur = start, rot = 0;
+    for (int step = 0;; ++step) {
+        ArgMin mine;
+        mine.d = DBL_MAX; mine.k = 0x7fffffff;
+        double mx = 0.0, my = 0.0;
+        // candidates four at a time: the LDS reads and the four distance chains overlap (one wave per SIMD
+        // has no other wave to hide latency behind); groups whose four candidates are all visited are skipped
+        for (int g = 0; g < M; g += 4) {
+            const unsigned nib = (unsigned)(alive >> g) & 0xFu;
+            if (!nib) continue;
+            double2 c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = s_xy[min(tid + (g + q) * kConsLdsThreads, n - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double d = dist_xy<WT, INT>(curx, cury, c[q].x, c[q].y);
+                if (((nib >> q) & 1u) && d < mine.d) {   // g, q ascend: the lowest index wins ties
+                    mine.d = d; mine.k = tid + (g + q) * kConsLdsThreads; mx = c[q].x; my = c[q].y;
+                }
+            }
+        }
+        ConsSlot best = cons_argmin(mine, mx, my, s_tab + rot * (kConsLdsThreads / 64));
+        rot = (rot + 1) & 3;
+        if constexpr (IS_GRASP) {
+            const double draw = u[step];
+            if (!(draw < kGraspPickBest) && best.k != 0x7fffffff) {
+                ArgMin m2;
+                m2.d = DBL_MAX; m2.k = 0x7fffffff;
+                double m2x = 0.0, m2y = 0.0;
+                for (int g = 0; g < M && tid + g * kConsLdsThreads < best.k; g += 4) {
+                    const unsigned nib = (unsigned)(alive >> g) & 0xFu;
+                    if (!nib) continue;
+                    double2 c[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c[q] = s_xy[min(tid + (g + q) * kConsLdsThreads, n - 1)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int k = tid + (g + q) * kConsLdsThreads;
+                        const double d = dist_xy<WT, INT>(curx, cury, c[q].x, c[q].y);
+                        if (((nib >> q) & 1u) && k < best.k && d < m2.d) { m2.d = d; m2.k = k; m2x = c[q].x; m2y = c[q].y; }
+                    }
+                }
+                const ConsSlot runner = cons_argmin(m2, m2x, m2y, s_tab + rot * (kConsLdsThreads / 64));
+                rot = (rot + 1) & 3;
+                if (runner.k != 0x7fffffff) best = runner;
+            }
+        }
+        if (best.k == 0x7fffffff) {  // every node visited: close the cycle
+            if (tid == 0) succ[cur] = start;
+            if constexpr (IS_GRASP) total += dist_xy<WT, INT>(curx, cury, c_start.x, c_start.y);  // heuristics.c:135
+            total += dist_xy<WT, INT>(curx, cury, c_start.x, c_start.y);                           // :74 / :152
+            break;
+        }
+        const int pick = best.k;
+        if ((pick & (kConsLdsThreads - 1)) == tid) {   // the owner retires the node and records the edge
+            alive &= ~(1ull << (pick / kConsLdsThreads));
+            succ[cur] = pick;
+        }
+        total += best.d;
+        cur = pick; curx = best.x; cury = best.y;
+    }
+    if (tid == 0) { obj[b] = total; status[b] = TSP_OK; }
+}
+
 // ---- distance matrix ------------------------------------------------------------------------
 // Block = kDmRows rows x 1024 columns.  Each lane keeps the coordinates of its 4 consecutive
 // columns in registers for all rows of the block, computes 4 entries per row and streams them out
@@ -204,14 +334,31 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         TSP_HIP_TRY(hipMalloc(&d_urand, sizeof(double) * (size_t)B * n));
         TSP_HIP_TRY(hipMemcpyAsync(d_urand, urand, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, s));
     }
+    const char *no_lds = getenv("TSP_CONSTRUCT_GLOBAL");
+    const size_t lds_bytes = 4 * (kConsLdsThreads / 64) * sizeof(ConsSlot) + sizeof(double2) * (size_t)n;
+    const bool use_lds = !(no_lds && *no_lds == '1') && n <= kConsLdsMaxN && lds_bytes <= (size_t)160 * 1024;
+    hipError_t attr_err = hipSuccess;
     TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
-        if (kind == TSP_CONSTRUCT_GRASP)
+        if (use_lds) {
+            if (kind == TSP_CONSTRUCT_GRASP) {
+                auto kf = k_construct_lds<WTC, INTC, true>;
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                hipLaunchKernelGGL(kf, dim3(B), dim3(kConsLdsThreads), lds_bytes, s, inst->d_coord, n, d_starts, d_urand,
+                                   d_succ, d_obj, d_status);
+            } else {
+                auto kf = k_construct_lds<WTC, INTC, false>;
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                hipLaunchKernelGGL(kf, dim3(B), dim3(kConsLdsThreads), lds_bytes, s, inst->d_coord, n, d_starts,
+                                   (const double *)nullptr, d_succ, d_obj, d_status);
+            }
+        } else if (kind == TSP_CONSTRUCT_GRASP)
             hipLaunchKernelGGL((k_construct<WTC, INTC, true>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
                                d_starts, d_urand, d_vis, d_succ, d_obj, d_status);
         else
             hipLaunchKernelGGL((k_construct<WTC, INTC, false>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
                                d_starts, (const double *)nullptr, d_vis, d_succ, d_obj, d_status);
     });
+    TSP_HIP_TRY(attr_err);
     std::vector<int> h_succ((size_t)B * n), h_status((size_t)B);
     TSP_HIP_TRY(hipMemcpyAsync(h_succ.data(), d_succ, sizeof(int) * (size_t)B * n, hipMemcpyDeviceToHost, s));
     TSP_HIP_TRY(hipMemcpyAsync(h_status.data(), d_status, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, s));

@@ -108,6 +108,27 @@ __device__ __forceinline__ double dist_xy(double ax, double ay, double bx, doubl
     }
 }
 
+// ---- cheap lower bound used to skip exact evaluations ------------------------------------------------
+// For the sqrt-based metrics the exact distance costs a correctly rounded root (or an exact integer
+// fix-up); the hardware's raw v_sqrt_f64 is ~4x cheaper and within r * 2^-23 of the true root r.  A
+// 2-opt scan only needs the exact delta of pairs that could beat the current bound, so it first forms
+// delta~ from raw roots and skips the pair when  delta~ - margin >= bound.  `margin` (computed per
+// instance on the host, tsp_dev_inst_create) covers the two raw-root errors plus the rounding that the
+// exact metric applies (nint: 0.5 per distance, ceil/ATT: < 1 per distance).  Every decision is still
+// taken on exact values; the filter only removes pairs that provably cannot change it.
+template <int WT>
+constexpr bool has_root_filter() {
+    return WT == WT_EUC_2D || WT == WT_CEIL_2D || WT == WT_ATT || WT == WT_EUC_2D_ICOORD ||
+           WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
+}
+
+template <int WT>
+__device__ __forceinline__ double approx_root_dist(double ax, double ay, double bx, double by) {
+    const double dx = ax - bx, dy = ay - by;
+    const double s = dx * dx + dy * dy;
+    return __builtin_amdgcn_sqrt((WT == WT_ATT || WT == WT_ATT_ICOORD) ? s * 0.1 : s);
+}
+
 // Runtime dispatch over (weight type, integer cost) -> template instance.
 #define TSP_DISPATCH_METRIC(WT_RT, INT_RT, ...)                                               \
     do {                                                                                      \

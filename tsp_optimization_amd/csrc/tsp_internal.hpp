@@ -53,6 +53,7 @@ struct tsp_dev_inst {
     int n = 0;
     int wtype = 0;        // kernel variant: unknown -> EUC_2D; *_ICOORD when the coordinates allow it
     int wtype_public = 0; // the caller's weight type
+    double filter_margin = 1e300; // root filter margin of the 2-opt scans (tsp_dist.hpp); 1e300 = off
     int integer_cost = 1;
     double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)

@@ -114,4 +114,10 @@ __device__ __forceinline__ double pair_delta(const NodeRec &a, const NodeRec &b)
     return dist_xy<WT, INT>(a.x, a.y, b.x, b.y) + dist_xy<WT, INT>(a.xs, a.ys, b.xs, b.ys) - a.ds - b.ds;
 }
 
+// delta~ of the same pair from raw roots (see has_root_filter in tsp_dist.hpp); ds of both nodes is exact.
+template <int WT>
+__device__ __forceinline__ double pair_delta_approx(const NodeRec &a, const NodeRec &b) {
+    return approx_root_dist<WT>(a.x, a.y, b.x, b.y) + approx_root_dist<WT>(a.xs, a.ys, b.xs, b.ys) - a.ds - b.ds;
+}
+
 }  // namespace tsp

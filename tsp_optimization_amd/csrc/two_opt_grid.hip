@@ -173,6 +173,7 @@ struct StepArgs {
     int *tabu;
     size_t partial_per_tour;
     int n, rows_per_block, first_min_rows, first_max_rows, count_evals, iter, tenure;
+    double margin;     // root filter (tsp_dist.hpp); 1e300 = every pair is evaluated exactly
 };
 
 template <int WT, bool INT, int MODE, int RJ, bool TABU>
@@ -401,35 +402,51 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     int bi = -1, bj = -1;
     int n_eval = 0;  // TABU: pairs that reach the delta expression (tabusearch.c:150)
     // rows in groups of RU: RU x RJ independent delta evaluations per lane keep the fp64 pipe fed
-    // (the sqrt refinement is a long dependent chain); FIRST leaves after the group with a hit
+    // (the root refinement is a long dependent chain); FIRST leaves after the group with a hit.
+    // Sqrt metrics: every pair first gets the raw-root lower bound (straight-line code, all RJ columns
+    // interleaved); the exact evaluation runs under one divergent branch for the few lanes that need it.
     constexpr int RU = (MODE == TSP_2OPT_FIRST) ? 4 : 1;
+    constexpr bool FILTER = has_root_filter<WT>();
     for (int ib = r0; ib < r1; ib += RU) {
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int i = min(ib + u, r1 - 1);
             const bool row_ok = ib + u < r1;
             const NodeRec ri = s_rows[i - r0];
+            bool ok[RJ];
+            bool any_ok = false;
 #pragma unroll
             for (int k = 0; k < RJ; ++k) {
                 const int j = jc[k];
-                bool ok = row_ok && j > i && j != ri.succ && rj[k].succ != i;  // heuristics.c:471 / tabusearch.c:134
-                if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
+                ok[k] = row_ok && j > i && j != ri.succ && rj[k].succ != i;  // heuristics.c:471 / tabusearch.c:134
+                if constexpr (MODE == TSP_2OPT_FIRST) ok[k] = ok[k] && (i > ci || j > cj);
                 if constexpr (TABU) {
-                    if (ok) {
+                    if (ok[k]) {
                         const int a1 = ri.succ, b1 = rj[k].succ;
                         if (stamp_is_tabu(a.tabu + udir_pos(i, j, n), a.iter, a.tenure) ||
                             stamp_is_tabu(a.tabu + udir_pos(i, a1, n), a.iter, a.tenure) ||
                             stamp_is_tabu(a.tabu + udir_pos(j, b1, n), a.iter, a.tenure) ||
                             stamp_is_tabu(a.tabu + udir_pos(i, b1, n), a.iter, a.tenure))
-                            ok = false;  // tabusearch.c:137-149
+                            ok[k] = false;  // tabusearch.c:137-149
                     }
-                    n_eval += ok ? 1 : 0;
+                    n_eval += ok[k] ? 1 : 0;
                 }
-                const double delta = pair_delta<WT, INT>(ri, rj[k]);
-                if constexpr (MODE == TSP_2OPT_FIRST) {
-                    if (ok && delta < 0 && bi < 0) { bd = delta; bi = i; bj = j; }  // keep the first in (i, j) order
-                } else {
-                    if (ok && delta < bd) { bd = delta; bi = i; bj = j; }
+                if constexpr (FILTER) {
+                    // a pair whose raw-root delta cannot get below the bound is not evaluated exactly
+                    const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
+                    ok[k] = ok[k] & (pair_delta_approx<WT>(ri, rj[k]) - a.margin < bound);   // '&': no branch
+                }
+                any_ok = any_ok || ok[k];
+            }
+            if (!FILTER || any_ok) {
+#pragma unroll
+                for (int k = 0; k < RJ; ++k) {
+                    const double delta = pair_delta<WT, INT>(ri, rj[k]);
+                    if constexpr (MODE == TSP_2OPT_FIRST) {
+                        if (ok[k] && delta < 0 && bi < 0) { bd = delta; bi = i; bj = jc[k]; }  // keep the first in (i, j) order
+                    } else {
+                        if (ok[k] && delta < bd) { bd = delta; bi = i; bj = jc[k]; }
+                    }
                 }
             }
         }
@@ -558,6 +575,7 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.first_max_rows = 0;
     a.count_evals = t->count_evals;
     a.iter = iter; a.tenure = tenure;
+    a.margin = t->inst->filter_margin;
     return a;
 }
 

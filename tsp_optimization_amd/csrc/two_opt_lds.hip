@@ -33,7 +33,7 @@ template <int WT, bool INT, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
-                                                             int rmax, int count_evals, int max_iters) {
+                                                             int rmax, int count_evals, int max_iters, double margin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
     double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
@@ -85,12 +85,22 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     const NodeRec ri = s_rows[r];
                     bool ok = j > i && j != ri.succ && rj.succ != i;  // heuristics.c:471 / tabusearch.c:134
                     if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
-                    const double delta = pair_delta<WT, INT>(ri, rj);
                     const u64 k = make_key(i, j);
-                    if constexpr (MODE == TSP_2OPT_FIRST) {
-                        if (ok && delta < 0 && k < key) { bd = delta; key = k; }
-                    } else {
-                        if (ok && better(delta, k, bd, key)) { bd = delta; key = k; }
+                    if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && k < key;
+                    if constexpr (has_root_filter<WT>()) {
+                        const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
+                        // a lane's keys are not visited in increasing order here, so BEST must keep ties
+                        // (an equal delta with a smaller key wins): skip only when provably greater
+                        const double lower = pair_delta_approx<WT>(ri, rj) - margin;
+                        ok = ok && (MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound);
+                    }
+                    if (ok) {
+                        const double delta = pair_delta<WT, INT>(ri, rj);
+                        if constexpr (MODE == TSP_2OPT_FIRST) {
+                            if (delta < 0) { bd = delta; key = k; }
+                        } else {
+                            if (better(delta, k, bd, key)) { bd = delta; key = k; }
+                        }
                     }
                 }
             }
@@ -215,13 +225,13 @@ hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_it
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters);
+                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin);
     } else {
         auto k = k_lds_two_opt<WT, INT, TSP_2OPT_BEST>;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters);
+                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin);
     }
     return hipGetLastError();
 }
