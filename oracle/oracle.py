@@ -58,6 +58,7 @@ def lib():
         L.orc_extramileage.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
         L.orc_two_opt_first.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_double, C.c_int,
                                         C.POINTER(Stats), C.POINTER(Move), C.c_longlong]
+        L.orc_two_opt_first_moves.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong, C.POINTER(Stats)]
         L.orc_two_opt_best.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, ip, C.c_int, C.c_int,
                                        ip, C.c_double, C.c_longlong, C.POINTER(Stats),
                                        C.POINTER(Move), C.c_longlong]
@@ -181,6 +182,16 @@ def two_opt_first(xy, wtype, succ, obj, integer_cost=1, time_limit=-1.0, clock_p
     status = lib().orc_two_opt_first(_d(xy), n, wtype, integer_cost, _i(succ), C.byref(o),
                                      time_limit, clock_per_pair, C.byref(st), tr, trace_cap)
     return status, succ, o.value, st.as_dict(), _trace_out(tr, st.moves, trace_cap)
+
+
+def two_opt_first_moves(xy, wtype, succ, obj, max_moves, integer_cost=1):
+    """-> (succ', obj', stats) after exactly max_moves moves of the first-improvement trajectory (or fewer at the optimum)"""
+    xy = _xy(xy)
+    succ = np.array(succ, dtype=np.int32, copy=True)
+    o = C.c_double(obj)
+    st = Stats()
+    lib().orc_two_opt_first_moves(_d(xy), len(xy), wtype, integer_cost, _i(succ), C.byref(o), max_moves, C.byref(st))
+    return succ, o.value, st.as_dict()
 
 
 def two_opt_best(xy, wtype, succ, obj=0.0, integer_cost=1, tabu=None, iter_=1, tenure=0,

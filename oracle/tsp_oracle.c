@@ -296,6 +296,42 @@ int orc_two_opt_first(const double *xy, int n, int wtype, int integer_cost, int 
     return status;
 }
 
+/* Harness helper: the first `max_moves` moves of orc_two_opt_first's trajectory (stops right after applying
+ * the max_moves-th move, mid-sweep), so that a device run stopped after the same number of moves can be
+ * compared tour for tour at sizes where the full descent takes the CPU too long. */
+int orc_two_opt_first_moves(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                            long long max_moves, orc_stats *st) {
+    orc_stats s = {0, 0, 0, 0, 0.0};
+    int *prev = malloc(sizeof(int) * (size_t)n);
+    rebuild_prev(n, succ, prev);
+    double seen_cost = *obj, cost = *obj;
+    int stop = max_moves <= 0;
+    while (!stop) {
+        for (int i = 0; i < n - 1 && !stop; i++)
+            for (int j = i + 1; j < n && !stop; j++) {
+                const int i_next = succ[i], j_next = succ[j];
+                if (i_next == j_next || i == j_next || j == i_next) continue;
+                s.evals++;
+                double delta = orc_dist(xy, i, j, wtype, integer_cost) + orc_dist(xy, i_next, j_next, wtype, integer_cost)
+                             - orc_dist(xy, i, i_next, wtype, integer_cost) - orc_dist(xy, j, j_next, wtype, integer_cost);
+                if (delta < 0) {
+                    succ[i] = j; succ[i_next] = j_next;
+                    s.reversed += reverse_walk(n, succ, j, i_next, prev);
+                    cost += delta;
+                    if (++s.moves >= max_moves) stop = 1;
+                }
+            }
+        if (stop) break;
+        s.sweeps++;
+        if (cost >= seen_cost) break;
+        seen_cost = cost;
+    }
+    *obj = cost;
+    free(prev);
+    if (st) *st = s;
+    return ORC_OK;
+}
+
 /* src/utility.c:17-30 */
 int orc_udir_pos(int i, int j, int n) {
     if (i > j) { int t = i; i = j; j = t; }

@@ -74,6 +74,10 @@ int orc_two_opt_first(const double *xy, int n, int wtype, int integer_cost, int 
                       double time_limit, int clock_per_pair, orc_stats *st, orc_move *trace,
                       long long trace_cap);
 
+/* Harness helper: the first max_moves moves of orc_two_opt_first (stops mid-sweep right after the last one). */
+int orc_two_opt_first_moves(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,
+                            long long max_moves, orc_stats *st);
+
 /* src/tabusearch.c:107-178 (best improvement; tabu == NULL gives plain best-improvement 2-opt).
  * max_sweeps < 0 = until local optimum (max_sweeps is a harness knob for bounded timing samples). */
 int orc_two_opt_best(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj,

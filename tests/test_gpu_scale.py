@@ -74,3 +74,39 @@ def test_best_improvement_rand10000_properties(eng, ctx):
     rc3, s3b, o3, st3b = inst.two_opt(s, o, mode=eng.FIRST)
     assert st3b["moves"] == 0 and st3b["sweeps"] == 1 and st3b["evals"] == 10000 * 9999 // 2 - 10000
     inst.close()
+
+
+@pytest.mark.parametrize("n,integer_coords", [(20011, True), (12007, False)])
+def test_large_odd_sizes_prefix_of_both_trajectories(eng, ctx, n, integer_coords):
+    """Sizes beyond the BASELINE configs (odd n, tiles that do not divide, general and integer-coordinate
+    variants): the first best-improvement sweeps and the first first-improvement moves equal the oracle's."""
+    rng = np.random.default_rng(n)
+    xy = rng.integers(0, 700_000, size=(n, 2)).astype(np.float64)
+    if not integer_coords:
+        xy = xy + rng.integers(0, 4, size=(n, 2)) * 0.25
+    wt = O.EUC_2D
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ0, obj0, _ = inst.construct(eng.GREEDY, np.array([7], dtype=np.int32))
+    _, es0, eo0 = O.greedy(xy, wt, start=7)
+    assert obj0[0] == eo0 and (succ0[0] == es0).all()
+    tours = eng.Tours(inst, 1)
+    # best improvement: 2 sweeps
+    tours.upload(es0, eo0)
+    tours.run(eng.BEST, max_steps=2)
+    s, _, st = tours.download()
+    _, eb, _, _, _, _ = O.two_opt_best(xy, wt, es0, max_sweeps=2)
+    assert (s[0] == eb).all() and st[0]["moves"] == 2
+    # first improvement: step until 25 moves have been applied
+    tours.reset()
+    moves = 0
+    for _ in range(400):
+        tours.run(eng.FIRST, max_steps=1)
+        s, o, st = tours.download()
+        moves = st[0]["moves"]
+        if moves >= 25:
+            break
+    assert moves == 25
+    ef, eof, est = O.two_opt_first_moves(xy, wt, es0, eo0, 25)
+    assert (s[0] == ef).all() and o[0] == eof and st[0]["reversed"] == est["reversed"]
+    tours.close()
+    inst.close()
