@@ -80,6 +80,40 @@ def test_cli_help_and_methods(built):
     assert r.returncode == 0 and "-method <type>" in r.stdout
 
 
+def test_reference_ctest_cases_for_the_parser(built):
+    """The reference's own CTest cases (test/CMakeLists.txt:6-19): no args fails, --help and --v succeed, a
+    missing file fails, a file whose header fields are shuffled still parses, a file without DIMENSION
+    fails.  Without a GPU the shuffled file gets past the parser and stops at the device."""
+    from tsp_optimization_amd.build import lib_path
+    from tsp_optimization_amd import engine as E
+    tsp = lib_path("tsp")
+    inst = os.path.join(ROOT, "tests/golden/instances")
+    run = lambda *a: subprocess.run([tsp] + list(a), capture_output=True, text=True)
+    assert run().returncode == 1
+    assert run("--help").returncode == 0
+    r = run("--v")
+    assert r.returncode == 0 and r.stdout.startswith("Version")
+    r = run("-f", "hello.txt", "-method", "GREEDY")
+    assert r.returncode == 1 and "Unable to open file" in r.stderr
+    r = run("-f", os.path.join(inst, "fail_att48.tsp"), "-method", "GREEDY", "-verbose", "3")
+    assert r.returncode == 1 and "unknown node" in r.stderr            # no DIMENSION before the coordinates
+    r = run("-f", os.path.join(inst, "shuffled_prop_att48.tsp"), "-method", "GREEDY", "--perfprof")
+    if E.device_count() == 0:
+        assert r.returncode == 1 and "tsp_dev_open" in r.stderr        # parsed; no device to run on
+    else:
+        assert r.returncode == 0 and float(r.stdout) > 0
+
+
+def test_oracle_parser_on_the_reference_ctest_files():
+    from oracle import oracle as O
+    inst = os.path.join(ROOT, "tests/golden/instances")
+    xy, wt = O.parse_tsplib(os.path.join(inst, "shuffled_prop_att48.tsp"))
+    ref, wt_ref = O.parse_tsplib(os.path.join(inst, "att48.tsp"))
+    assert xy.shape == (48, 2) and (xy == ref).all() and wt_ref == O.ATT and wt == O.ATT
+    with pytest.raises(ValueError):
+        O.parse_tsplib(os.path.join(inst, "fail_att48.tsp"))
+
+
 def test_pack_orders_by_cost_then_start():
     from tsp_optimization_amd import multistart as M
     assert M.unpack(M.pack(28998, 122)) == (28998, 122)

@@ -110,3 +110,17 @@ def test_large_odd_sizes_prefix_of_both_trajectories(eng, ctx, n, integer_coords
     assert (s[0] == ef).all() and o[0] == eof and st[0]["reversed"] == est["reversed"]
     tours.close()
     inst.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_time_limit_stops_with_a_valid_tour_and_status_2(eng, ctx, mode):
+    """TIME_LIMIT_EXCEEDED (include/heuristics.h:7): the descent stops between launch batches with a valid tour;
+    alg_2opt's obj_best still equals start + applied deltas, alg_2opt_tabu's is the recomputed cost (:168-172)."""
+    xy, wt = load_instance("rand10000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    rc, s, o, st = inst.two_opt(succ0, obj0, mode=mode, engine=eng.ENGINE_GRID, time_limit=0.004)
+    inst.close()
+    assert rc == eng.TIME_LIMIT_EXCEEDED
+    assert O.is_tour(s) and 0 < st["moves"] < (2704 if mode == 0 else 1427)
+    assert o == O.succ_cost(xy, wt, s) and o < obj0

@@ -92,6 +92,8 @@ struct tsp_dev_tours {
     int first_max_rows = 2048;
     int best_rows_per_block = 32;
     int count_evals = 1;             // FIRST: keep the reference-equivalent evaluation counter
+    int use_graph = 0;               // replay full batches of steps from a captured hipGraph
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // per mode
     // accumulated device time
     double device_ms = 0.0;
 };

@@ -657,10 +657,30 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         int64_t todo = batch;
         if (max_steps >= 0) todo = std::min<int64_t>(batch, max_steps - queued);
         if (todo <= 0) break;
-        for (int64_t k = 0; k < todo; ++k) {
-            int rc = launch_step_rt(t, mode, tabu, iter, tenure);
-            if (rc) return rc;
+        // A full batch of identical launches is replayed from a captured hipGraph (the kernel arguments
+        // never change: the descent is driven by the device-resident control block); partial batches and
+        // tabu runs (iter/tenure change per call) are launched directly.
+        bool replayed = false;
+        if (todo == batch && !tabu && t->use_graph) {
+            hipGraphExec_t &exec = t->graph_exec[mode];
+            if (!exec) {
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    for (int64_t k = 0; k < batch; ++k) launch_step_rt(t, mode, nullptr, 0, 0);
+                    if (hipStreamEndCapture(s, &g) == hipSuccess && g) {
+                        if (hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) != hipSuccess) exec = nullptr;
+                        (void)hipGraphDestroy(g);
+                    }
+                }
+                if (!exec) { (void)hipGetLastError(); t->use_graph = 0; }
+            }
+            if (exec) { TSP_HIP_TRY(hipGraphLaunch(exec, s)); replayed = true; }
         }
+        if (!replayed)
+            for (int64_t k = 0; k < todo; ++k) {
+                int rc = launch_step_rt(t, mode, tabu, iter, tenure);
+                if (rc) return rc;
+            }
         queued += todo;
         TSP_HIP_TRY(hipGetLastError());
         if (!sync) continue;
@@ -718,6 +738,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     }
     t->best_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_BEST_ROWS_PER_BLOCK", 32)));
     t->count_evals = env_int("TSP_COUNT_EVALS", 1);
+    t->use_graph = env_int("TSP_USE_GRAPH", 0);
     const size_t bn = (size_t)B * inst->n;
     const dim3 gb = scan_grid<TSP_2OPT_BEST>(t), gf = scan_grid<TSP_2OPT_FIRST>(t);
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
@@ -745,6 +766,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
+    for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
     delete t;
 }
 
