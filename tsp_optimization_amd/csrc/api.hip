@@ -21,6 +21,20 @@ void set_last_error(const char *what, hipError_t e, const char *file, int line) 
 }
 }  // namespace tsp
 
+// Single-tour calls (alg_2opt in a VNS / tabu / GA loop) reuse one tours handle and one event pair per
+// instance instead of eight hipMallocs per call.  Handles are per instance: not for concurrent use.
+tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc) {
+    *owned = false; *rc = TSP_OK;
+    if (B == 1) {
+        if (!inst->scratch1) { *rc = tsp_dev_tours_create(inst, 1, &inst->scratch1); if (*rc) return nullptr; }
+        return inst->scratch1;
+    }
+    tsp_dev_tours *t = nullptr;
+    *rc = tsp_dev_tours_create(inst, B, &t);
+    *owned = true;
+    return t;
+}
+
 namespace {
 double wall_s() {
     struct timespec ts;
@@ -185,6 +199,8 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     if (!inst) return;
     (void)hipSetDevice(inst->ctx->device);
     (void)hipStreamSynchronize(inst->ctx->stream);
+    if (inst->scratch1) tsp_dev_tours_destroy(inst->scratch1);
+    if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
     (void)hipFree(inst->d_coord);
     delete inst;
 }
@@ -279,14 +295,14 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     const double t0 = wall_s();
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    tsp_dev_tours *t = nullptr;
-    int rc = tsp_dev_tours_create(inst, B, &t);
+    bool owned = false;
+    int rc = TSP_OK;
+    tsp_dev_tours *t = tsp_scratch_tours(inst, B, &owned, &rc);
     if (rc) return rc;
     rc = tsp_dev_tours_upload(t, succ, succ_stride, tour_stride, obj);
-    if (rc) { tsp_dev_tours_destroy(t); return rc; }
-    hipEvent_t e0, e1;
-    TSP_HIP_TRY(hipEventCreate(&e0));
-    TSP_HIP_TRY(hipEventCreate(&e1));
+    if (rc) { if (owned) tsp_dev_tours_destroy(t); return rc; }
+    if (!inst->ev0) { TSP_HIP_TRY(hipEventCreate(&inst->ev0)); TSP_HIP_TRY(hipEventCreate(&inst->ev1)); }
+    hipEvent_t e0 = inst->ev0, e1 = inst->ev1;
     TSP_HIP_TRY(hipEventRecord(e0, s));
     int done = 0;
     int status = engine == TSP_ENGINE_LDS ? tsp_lds_run(t, mode, time_limit_s, &done)
@@ -295,8 +311,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     TSP_HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     TSP_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (status < 0) { tsp_dev_tours_destroy(t); return status; }
+    if (status < 0) { if (owned) tsp_dev_tours_destroy(t); return status; }
     std::vector<double> new_obj((size_t)B);
     rc = tsp_dev_tours_download(t, succ, succ_stride, tour_stride, new_obj.data(), stats);
     if (rc == TSP_OK) {
@@ -306,7 +321,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         }
         if (stats) for (int b = 0; b < B; ++b) { stats[b].seconds = wall_s() - t0; stats[b].device_ms = ms; }
     }
-    tsp_dev_tours_destroy(t);
+    if (owned) tsp_dev_tours_destroy(t);
     return rc ? rc : status;
 }
 

@@ -48,11 +48,14 @@ struct tsp_dev_ctx {
     int lds_bytes = 0;
 };
 
+struct tsp_dev_tours;
 struct tsp_dev_inst {
     tsp_dev_ctx *ctx = nullptr;
     int n = 0;
     int wtype = 0;        // kernel variant: unknown -> EUC_2D; *_ICOORD when the coordinates allow it
     int wtype_public = 0; // the caller's weight type
+    tsp_dev_tours *scratch1 = nullptr;  // reusable single-tour handle of the host-tour entry points (B == 1)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // reusable timing events
     double filter_margin = 1e300; // root filter margin of the 2-opt scans (tsp_dist.hpp); 1e300 = off
     int integer_cost = 1;
     double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO

@@ -710,6 +710,8 @@ int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
     return TSP_OK;
 }
 
+tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc);   // api.hip
+
 extern "C" {
 
 int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
@@ -979,16 +981,16 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
     if (tabu && tabu->inst != inst) return TSP_DEV_E_ARG;
     const double t0 = wall_s();
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
-    tsp_dev_tours *t = nullptr;
-    int rc = tsp_dev_tours_create(inst, 1, &t);
+    bool owned = false;
+    int rc = TSP_OK;
+    tsp_dev_tours *t = tsp_scratch_tours(inst, 1, &owned, &rc);
     if (rc) return rc;
     rc = tsp_dev_tours_upload(t, succ, succ_stride, inst->n, obj);
-    if (rc) { tsp_dev_tours_destroy(t); return rc; }
+    if (rc) return rc;
     int done = 0;
     const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 1, &done);
-    if (status < 0) { tsp_dev_tours_destroy(t); return status; }
+    if (status < 0) return status;
     rc = tsp_dev_tours_download(t, succ, succ_stride, inst->n, obj, stats);
-    tsp_dev_tours_destroy(t);
     if (rc) return rc;
     if (stored_prev)  // tabusearch.c:173-175
         for (int v = 0; v < inst->n; ++v) stored_prev[succ[(size_t)v * succ_stride]] = v;
