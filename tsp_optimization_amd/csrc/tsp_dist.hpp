@@ -125,7 +125,7 @@ constexpr bool has_root_filter() {
 template <int WT>
 __device__ __forceinline__ double approx_root_dist(double ax, double ay, double bx, double by) {
     const double dx = ax - bx, dy = ay - by;
-    const double s = dx * dx + dy * dy;
+    const double s = fma(dx, dx, dy * dy);   // a bound, not a reference value: the fused form is fine here
     return __builtin_amdgcn_sqrt((WT == WT_ATT || WT == WT_ATT_ICOORD) ? s * 0.1 : s);
 }
 

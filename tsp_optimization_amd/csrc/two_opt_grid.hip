@@ -407,6 +407,35 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     // interleaved); the exact evaluation runs under one divergent branch for the few lanes that need it.
     constexpr int RU = (MODE == TSP_2OPT_FIRST) ? 4 : 1;
     constexpr bool FILTER = has_root_filter<WT>();
+    // Interior tiles of a BEST sweep on integer-valued costs need no per-pair predicate at all: every column
+    // is a valid node above every row of the tile, and an adjacent pair has delta == 0 exactly
+    // (d(a,b) = d(a,a1), d(a1,b1) = d(b,b1) and integer sums are exact), which the strict '<' never takes
+    // (heuristics.c:471 / tabusearch.c:134 exist to skip exactly those).  Non-integer costs keep the test:
+    // there (x + y) - x - y can round to a tiny negative.
+    constexpr bool EXACT_SUMS = INT || WT == WT_CEIL_2D || WT == WT_CEIL_2D_ICOORD;
+    const bool plain_tile = MODE == TSP_2OPT_BEST && !TABU && FILTER && EXACT_SUMS && c0 >= r1 && c0 + TJ <= n;
+    if (plain_tile) {
+        for (int i = r0; i < r1; ++i) {
+            const NodeRec ri = s_rows[i - r0];
+            const double row_bias = ri.ds + a.margin;
+            bool need[RJ];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < RJ; ++k) {
+                const double lower = approx_root_dist<WT>(ri.x, ri.y, rj[k].x, rj[k].y) +
+                                     approx_root_dist<WT>(ri.xs, ri.ys, rj[k].xs, rj[k].ys) - row_bias - rj[k].ds;
+                need[k] = lower < bd;
+                any = any || need[k];
+            }
+            if (any) {
+#pragma unroll
+                for (int k = 0; k < RJ; ++k) {
+                    const double delta = pair_delta<WT, INT>(ri, rj[k]);
+                    if (need[k] && delta < bd) { bd = delta; bi = i; bj = jc[k]; }
+                }
+            }
+        }
+    } else
     for (int ib = r0; ib < r1; ib += RU) {
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
