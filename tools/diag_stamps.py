@@ -25,3 +25,4 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
     for k in range(1, 10):
         print('  %-28s %7.2f us' % (names[k - 1], buf[k] / 100.0)); tot += buf[k] / 100.0
     print('  %-28s %7.2f us' % ('sum (last block lifetime)', tot))
+    print('  shader clock during row loops: %.0f MHz; row-loop block-us total %.0f (=> per step %.1f block-us)' % (buf[15], buf[14], buf[14] / max(n, 1) if False else buf[14] / max(st['steps'], 1)))

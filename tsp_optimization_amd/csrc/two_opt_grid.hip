@@ -34,6 +34,7 @@ constexpr int kMaxRowsPerBlock = 64;
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_stamp_sum[16];
 __device__ unsigned long long g_stamp_n;
+__device__ unsigned long long g_clk_core, g_clk_real;   // row-loop time of every block: shader cycles vs 100 MHz ticks
 #define TSP_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
 #else
 #define TSP_STAMP(k) do { } while (0)
@@ -207,7 +208,7 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
     double bd = 0.0;
     u64 key = kNoKey;
     long long tabu_evals = 0;
-    constexpr int PU = 8;
+    constexpr int PU = 4;
     for (int s0 = tid; s0 < nslots; s0 += PU * kScanThreads) {
         double pd[PU]; int pi[PU], pj[PU]; bool live[PU];
 #pragma unroll
@@ -267,7 +268,7 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
     if (found) {
         L = pb - pa; if (L < 0) L += n;
         const int half = L >> 1;
-        constexpr int U = 8;
+        constexpr int U = 4;
         for (int t0 = tid; t0 < half; t0 += U * kScanThreads) {
             int p[U], q[U], u[U], w[U];
 #pragma unroll
@@ -397,6 +398,9 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     }
     __syncthreads();
     TSP_STAMP(1);
+#ifdef TSP_STAMPS
+    const unsigned long long clk0 = clock64(), rt0 = wall_clock64();
+#endif
 
     double bd = 0.0;
     int bi = -1, bj = -1;
@@ -489,6 +493,9 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     __shared__ u64 s_k[kScanThreads / 64];
     __shared__ int s_cnt[kScanThreads / 64];
     __shared__ int s_last;
+#ifdef TSP_STAMPS
+    if (tid == 0) { atomicAdd(&g_clk_core, clock64() - clk0); atomicAdd(&g_clk_real, wall_clock64() - rt0); }
+#endif
     TSP_STAMP(2);
     block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
     TSP_STAMP(3);
@@ -1034,9 +1041,16 @@ int tsp_dev_debug_stamps(double *out16) {
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tsp::g_stamp_sum), sizeof h) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(&nn, HIP_SYMBOL(tsp::g_stamp_n), sizeof nn) != hipSuccess) return -1;
     for (int k = 0; k < 16; ++k) out16[k] = nn ? (double)h[k] / (double)nn : 0.0;
+    unsigned long long cc = 0, rr = 0;
+    (void)hipMemcpyFromSymbol(&cc, HIP_SYMBOL(tsp::g_clk_core), sizeof cc);
+    (void)hipMemcpyFromSymbol(&rr, HIP_SYMBOL(tsp::g_clk_real), sizeof rr);
+    out16[15] = rr ? (double)cc / (double)rr * 100.0 : 0.0;   // MHz during the row loops
+    out16[14] = nn ? (double)rr / 100.0 : 0.0;                // total row-loop block-microseconds
     unsigned long long z[16] = {0}, zn = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_stamp_sum), z, sizeof z);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_stamp_n), &zn, sizeof zn);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_clk_core), &zn, sizeof zn);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_clk_real), &zn, sizeof zn);
     return (int)nn;
 }
 #endif
