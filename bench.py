@@ -34,6 +34,57 @@ def rand_instance(n):
     return np.random.default_rng(n).integers(0, 1_000_000, size=(n, 2)).astype(np.float64)
 
 
+def other_configs(E, ctx, O):
+    """BASELINE configs[3] and [4] on this GPU (reported next to the headline; parity-checked inline)."""
+    res = {}
+    # configs[3]: att532, 256 GRASP starts (seed 123, stream order of heuristics.c:519 then :127) + alg_2opt each
+    xy, wt = O.parse_tsplib(os.path.join(ROOT, "tests", "golden", "instances", "att532.tsp"))
+    n = len(xy)
+    inst = E.Instance(ctx, xy, wt, 1)
+    O.srandom(123)
+    B = 256
+    starts = np.zeros(B, dtype=np.int32)
+    urand = np.zeros((B, n))
+    for b in range(B):
+        starts[b] = int(O.urand() * (n - 1))
+        urand[b] = [O.urand() for _ in range(n)]
+    inst.two_opt(*inst.construct(E.GRASP, starts[:8], urand[:8])[:2], mode=E.FIRST)   # warm
+    t0 = time.perf_counter()
+    succ, obj, _ = inst.construct(E.GRASP, starts, urand)
+    t1 = time.perf_counter()
+    rc, s2, o2, st = inst.two_opt(succ, obj, mode=E.FIRST)
+    t2 = time.perf_counter()
+    true_cost = inst.perm_cost(np.stack([O.succ_to_perm(s) for s in s2]))
+    k = int(np.lexsort((np.arange(B), true_cost))[0])
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")) as f:
+        table = json.load(f)["att532_multistart256"]
+    res["config4_att532_grasp256_2opt"] = {
+        "construct_ms": 1e3 * (t1 - t0), "two_opt_ms": 1e3 * (t2 - t1), "best_true_cost": float(true_cost[k]),
+        "best_start": k, "reference_best": [28998, 122],
+        "all_256_tours_match_golden": bool(all(O.fnv1a(s2[i]) == table[i]["hash"] for i in range(B))),
+        "reference_equivalent_evals": int(sum(x["evals"] for x in st)),
+        "cpu_reference_s": 27.6, "cpu_reference_note": "SURVEY.md section 6, unmodified reference, one core"}
+    inst.close()
+    # configs[4]: synthetic n=5000, 128 random individuals (genetic.c:349-364) each refined by alg_2opt
+    xy = rand_instance(5000)
+    inst = E.Instance(ctx, xy, E.EUC_2D, 1)
+    O.srandom(123)
+    perms = np.stack([O.random_perm(5000) for _ in range(128)])
+    succ = np.stack([O.perm_to_succ(p) for p in perms])
+    t0 = time.perf_counter()
+    cost = inst.perm_cost(perms)
+    t1 = time.perf_counter()
+    rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST)
+    t2 = time.perf_counter()
+    ev = int(sum(x["evals"] for x in st))
+    res["config5_rand5000_population128_2opt"] = {
+        "fitness_ms": 1e3 * (t1 - t0), "two_opt_s": t2 - t1, "reference_equivalent_evals": ev,
+        "reference_equivalent_evals_per_s": ev / (t2 - t1), "moves": int(sum(x["moves"] for x in st)),
+        "best_cost": float(o2.min()), "costs_equal_recomputed": bool((o2 == inst.perm_cost(np.stack([O.succ_to_perm(s) for s in s2]))).all())}
+    inst.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +244,7 @@ def main():
             "recomputed_cost_match": bool(o2 == O.succ_cost(xy, wt, s2)), "sweeps": st2["sweeps"],
             "evals": st2["evals"], "moves": st2["moves"], "evals_per_s": st2["evals"] / dt2}
         out["time_to_local_optimum"] = extras
+        out["other_configs"] = other_configs(E, ctx, O)
         # the genuinely HBM-bound kernel of the path: n x n calc_dist matrix (4 n^2 bytes written)
         _, dm_ms = inst.dist_matrix(as_int32=True, fetch=False)
         _, dm64_ms = inst.dist_matrix(as_int32=False, fetch=False)
