@@ -489,3 +489,18 @@ def test_root_filter_on_and_off_give_identical_descents(eng, ctx, monkeypatch):
         for a, b in zip(out["1"], out["0"]):
             assert (a[1] == b[1]).all() and a[2] == b[2], name
             assert (a[3]["sweeps"], a[3]["evals"], a[3]["moves"]) == (b[3]["sweeps"], b[3]["evals"], b[3]["moves"]), name
+
+
+@pytest.mark.parametrize("name", ["ali535", "gr431", "gr666"])
+def test_geo_instances_within_the_stated_tolerance(eng, ctx, name):
+    """GEO (cos/acos, distutil.c:60-71) is the tolerance tier: a few distances differ by one unit between
+    ocml and glibc, so trajectories may part ways.  Stated tolerance: constructive and 2-opt costs within
+    0.5 % of the reference's published values; tours valid; cost == recomputed cost on the device metric."""
+    xy, wt, inst = make_inst(eng, ctx, name)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+    assert abs(obj[0] - REF[name]["GREEDY"]) <= 0.005 * REF[name]["GREEDY"]
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=eng.FIRST)
+    assert O.is_tour(s) and abs(o - REF[name]["2OPT_GREEDY"]) <= 0.005 * REF[name]["2OPT_GREEDY"]
+    perm = O.succ_to_perm(s)
+    assert o == inst.perm_cost(perm)[0]
+    inst.close()
