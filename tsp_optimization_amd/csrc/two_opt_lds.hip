@@ -1,4 +1,4 @@
-// two_opt_lds.hip -- LDS engine: one 1024-thread workgroup per tour, the whole 2-opt descent inside
+// two_opt_lds.hip -- LDS engine: one 512-thread workgroup per tour, the whole 2-opt descent inside
 // one launch.  Same semantics, same control block and same counters as the GRID engine
 // (two_opt_grid.hip); what changes is where the state lives and who synchronises:
 //
@@ -8,7 +8,7 @@
 //   (GRASP multi-start, population refinement) are no longer launch-latency bound.
 //
 // Per step the block scans rows [ci, ci+R) (FIRST, R adaptive 1..32) or every row in blocks of 32
-// (BEST): lanes own columns j = tid + 1024 m, derive the column's NodeRec from LDS once per row
+// (BEST): lanes own columns j = tid + 512 m, derive the column's NodeRec from LDS once per row
 // block and evaluate it against the row records (LDS broadcast).  The winner is a block arg-min;
 // the move is a parallel swap loop on the LDS arrays.
 #include "two_opt_common.hpp"
@@ -20,7 +20,7 @@
 
 namespace tsp {
 
-constexpr int kLdsThreads = 1024;
+constexpr int kLdsThreads = 512;
 constexpr int kLdsRows = 32;
 using idx_t = unsigned short;
 
