@@ -159,6 +159,28 @@ def test_alg_2opt_tabu_with_host_stamp_array(host):
     assert h.obj == APB["pr299"]["best"]["cost"]
 
 
+NON_GEO = sorted(k for k in REF if k not in ("ali535", "gr431", "gr666"))
+
+
+@pytest.mark.parametrize("name", NON_GEO)
+def test_every_reproducible_cell_of_the_reference_tables(host, name):
+    """All seven deterministic columns of results/constructive_heuristics{_new,_2opt_new}.csv (seed 123) for
+    one instance, through the reference's own function names on the reference's instance struct."""
+    host.HEU_extramileage.argtypes = [C.POINTER(Instance)]
+    host.HEU_2opt_extramileage.argtypes = [C.POINTER(Instance)]
+    want = REF[name]
+    h = HostInstance(name)
+    assert host.HEU_greedy(C.byref(h.c)) == 0 and h.obj == want["GREEDY"]
+    assert host.HEU_2opt_greedy(C.byref(h.c)) == 0 and h.obj == want["2OPT_GREEDY"]
+    assert host.HEU_Greedy_iter(C.byref(h.c)) == 0 and h.obj == want["GREEDY_ITER"]
+    assert host.HEU_2opt_greedy_iter(C.byref(h.c)) == 0 and h.obj == want["2OPT_GREEDY_ITER"]
+    assert host.HEU_extramileage(C.byref(h.c)) == 0 and h.obj == want["EXTR_MILE"]
+    assert host.HEU_2opt_extramileage(C.byref(h.c)) == 0 and h.obj == want["2OPT_EXTR_MIL"]
+    O.srandom(123)
+    assert host.HEU_Grasp(C.byref(h.c)) == 0 and h.obj == want["GRASP"]
+    assert O.is_tour(h.succ)
+
+
 def test_fitness_batch(host):
     h = HostInstance("d493")
     rng = np.random.default_rng(4)
