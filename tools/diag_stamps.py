@@ -1,4 +1,9 @@
-"""Diagnostic build only (lib_diag, -DTSP_STAMPS): where a FIRST/BEST step's last block spends its time."""
+"""Diagnostic build only (lib_diag, -DTSP_STAMPS): where a FIRST/BEST step's last block spends its time,
+and the shader clock during the row loops.  Build it first (never shipped, never timed as the product):
+
+  make -C tsp_optimization_amd/csrc OUT=../lib_diag -j8 \
+       HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wall -Wno-unused-function -DTSP_STAMPS"
+"""
 import os, sys, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
