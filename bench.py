@@ -206,6 +206,20 @@ def main():
         if os.path.exists(tj):
             with open(tj) as f:
                 traffic = json.load(f).get("k_step_best_n10000_hbm_bytes_per_launch")
+        # transparency: the same sweep with the new-edge bound off (every pair gets both raw roots) and with
+        # both bounds off (every pair gets the exact delta), on a fresh copy of the same start tour
+        variants = {}
+        for label, env in (("no_new_edge_bound", {"TSP_NO_PRUNE": "1"}), ("every_pair_exact", {"TSP_NO_FILTER": "1"})):
+            os.environ.update(env)
+            inst_v = E.Instance(ctx, xy, wt, 1)
+            for k in env:
+                del os.environ[k]
+            tours_v = E.Tours(inst_v, 1)
+            tours_v.upload(succ0[0], obj0[0])
+            ms_v, ev_v = tours_v.time_scan(reps=30)
+            variants[label] = {"kernel_ms": ms_v, "evals_per_s": ev_v / (ms_v * 1e-3)}
+            tours_v.close()
+            inst_v.close()
         out["roofline"] = {
             "kernel": "tsp::k_step<EUC_2D integer-coordinate variant, BEST, RJ=2> (one sweep + move, n=10000)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -214,13 +228,16 @@ def main():
             "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
             "note": "achieved = evals/launch x 72 B (operands the reference touches per delta evaluation) / "
                     "kernel time; the tiled sweep re-uses operands on chip, so real HBM traffic (traffic) is "
-                    "far below it and frac can exceed 1: the kernel is fp64-VALU bound, see DESIGN.md",
-            "valu": {"issue_cycles_per_eval": 92, "simd_cycles_per_s_needed": evals_per_launch * 92 / 64 / (ms * 1e-3),
-                     "simd_cycles_per_s_available": 1024 * 2.4e9,
-                     "frac": evals_per_launch * 92 / 64 / (ms * 1e-3) / (1024 * 2.4e9),
-                     "note": "common path of one evaluation in k_step<6,...> = 15 fp64 VALU instructions (4 cycles per "
-                             "wave64 each) + 2 v_sqrt_f64 (16 cycles each, measured by tools/ubench/ops.hip) = 92 issue "
-                             "cycles per wave of 64 evaluations; 1024 SIMDs at the 2.4 GHz nominal clock"},
+                    "far below it and frac can exceed 1: the kernel is fp64-VALU bound, see DESIGN.md.  An "
+                    "evaluation = one pair decided exactly as the reference decides it; two rigorous lower bounds "
+                    "(new-edge bound, raw-root bound) let most pairs be decided without the exact roots -- "
+                    "`variants` gives the same sweep with them switched off",
+            "variants": variants,
+            "valu": {"measured": "profiles/r01_pmc_sq_wave_counters.json",
+                     "note": "rocprofv3 SQ counters of this kernel: ~16 VALU wave-instructions per wave of 64 "
+                             "evaluations (common path: 2 sub, mul, fma, add, mul, 2 compares), SQ_ACTIVE_INST_VALU "
+                             "~ 50-65 % of the launch's SIMD-cycles; the rest of a wave's life is the synchronised "
+                             "tile prologue / epilogue phases"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:

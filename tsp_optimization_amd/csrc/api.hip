@@ -175,6 +175,12 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
                 const double rounding = (inst->integer_cost || inst->wtype == TSP_CEIL_2D) ? 2.0 : 0.0;
                 inst->filter_margin = 2.0 * span * 0x1p-22 + rounding + 1e-6 + span * 0x1p-40;
             }
+            // new-edge bound: nint() can shorten the new edge by at most 1/2 (ceil / ATT never shorten it);
+            // the slack covers the rounding of s, T*T and the sums for coordinates of this magnitude
+            const char *nop = getenv("TSP_NO_PRUNE");
+            inst->prune_margin = 1e300;
+            if (sqrt_metric && !(nop && *nop == '1') && !(nof && *nof == '1') && span < 1e100)
+                inst->prune_margin = ((inst->integer_cost && inst->wtype == TSP_EUC_2D) ? 0.5 : 0.0) + 1e-6 + span * 0x1p-36;
         }
         const char *off = getenv("TSP_NO_ICOORD");
         if (all_int && span < TSP_ICOORD_MAX_DIST && !(off && *off == '1')) {

@@ -48,6 +48,7 @@ struct tsp_dev_ctx {
     int lds_bytes = 0;
 };
 
+namespace tsp { struct NodeRec; }
 struct tsp_dev_tours;
 struct tsp_dev_inst {
     tsp_dev_ctx *ctx = nullptr;
@@ -57,6 +58,7 @@ struct tsp_dev_inst {
     tsp_dev_tours *scratch1 = nullptr;  // reusable single-tour handle of the host-tour entry points (B == 1)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // reusable timing events
     double filter_margin = 1e300; // root filter margin of the 2-opt scans (tsp_dist.hpp); 1e300 = off
+    double prune_margin = 1e300;  // new-edge bound margin (tsp_dist.hpp); 1e300 = off
     int integer_cost = 1;
     double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
@@ -78,6 +80,7 @@ struct tsp_dev_tours {
     tsp::TourState *d_state = nullptr;
     tsp::Partial *d_partial = nullptr;
     size_t partial_per_tour = 0;
+    tsp::NodeRec *d_rec = nullptr;   // B x n node records, rebuilt before every BEST step (k_recs)
     int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
     int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)
     tsp::Partial *d_row_slot = nullptr;
@@ -95,6 +98,7 @@ struct tsp_dev_tours {
     int first_max_rows = 2048;
     int best_rows_per_block = 32;
     int count_evals = 1;             // FIRST: keep the reference-equivalent evaluation counter
+    int use_recs = 1;                // BEST: materialise the node records once per step (k_recs)
     int use_graph = 0;               // replay full batches of steps from a captured hipGraph
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // per mode
     // accumulated device time

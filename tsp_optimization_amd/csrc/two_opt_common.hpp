@@ -25,6 +25,10 @@ __device__ __forceinline__ bool better(double d1, u64 k1, double d2, u64 k2) {
 // BY_DELTA: arg-min of (delta, key); else: min key (first improving pair), delta rides along.
 template <bool BY_DELTA>
 __device__ __forceinline__ void wave_argmin(double &d, u64 &k) {
+    // Almost every wave of a scan has no candidate at all (one move per sweep): one ballot instead of
+    // eighteen cross-lane moves.  A wave with no key keeps (d, kNoKey) in every lane, which is what the
+    // reduction would have produced for the key; callers only use d together with a valid key.
+    if (!__any(k != kNoKey)) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const double od = __shfl_xor(d, off);

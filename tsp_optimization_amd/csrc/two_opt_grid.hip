@@ -27,7 +27,7 @@
 
 namespace tsp {
 
-constexpr int kMaxRowsPerBlock = 64;
+constexpr int kMaxRowsPerBlock = 256;
 
 // Diagnostic build only (-DTSP_STAMPS): 100 MHz wall-clock stamps of the last block of each step,
 // accumulated into a buffer nothing else reads (cdna_hip_programming.md section 7, in-kernel stamps).
@@ -45,6 +45,23 @@ __global__ void k_build_pos(const int *__restrict__ orders, int *__restrict__ po
     if (p >= n) return;
     const size_t base = (size_t)blockIdx.y * n;
     poss[base + orders[base + p]] = p;
+}
+
+// ---- node records of a whole tour (BEST sweeps) ------------------------------------------------------------
+// A BEST sweep has ~n^2 / (rows x columns) tiles and every tile needs the NodeRec of its rows and columns:
+// deriving them per tile costs ~n^2 / 32 scattered gathers per sweep, which became the bottleneck once the
+// pair loop was pruned.  So each BEST step first materialises all n records (one small launch, 4 n gathers),
+// and the tiles read them as contiguous 48-byte loads.  FIRST steps touch few tiles and keep deriving.
+template <int WT, bool INT>
+__global__ __launch_bounds__(kScanThreads) void k_recs(const double2 *__restrict__ coord, const int *__restrict__ orders,
+                                                       const int *__restrict__ poss, const TourState *__restrict__ states,
+                                                       NodeRec *__restrict__ recs, int n) {
+    const int tour = blockIdx.y;
+    if (states[tour].done) return;
+    const int v = blockIdx.x * kScanThreads + threadIdx.x;
+    if (v >= n) return;
+    const size_t base = (size_t)tour * n;
+    recs[base + v] = load_node<WT, INT>(coord, orders + base, poss + base, n, v);
 }
 
 // ---- in-launch hand-off of the block candidates ---------------------------------------------
@@ -172,9 +189,11 @@ struct StepArgs {
     int max_tile_rows;
     int *slot_evals;   // tabu runs only
     int *tabu;
+    const NodeRec *recs;   // BEST: materialised by k_recs before the step; nullptr = derive per tile
     size_t partial_per_tour;
     int n, rows_per_block, first_min_rows, first_max_rows, count_evals, iter, tenure;
     double margin;     // root filter (tsp_dist.hpp); 1e300 = every pair is evaluated exactly
+    double prune;      // new-edge bound margin (tsp_dist.hpp); 1e300 = never prune
 };
 
 template <int WT, bool INT, int MODE, int RJ, bool TABU>
@@ -387,14 +406,25 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     const int *pos = a.poss + (size_t)tour * n;
 
     __shared__ NodeRec s_rows[kMaxRowsPerBlock];
-    if (tid < r1 - r0) s_rows[tid] = load_node<WT, INT>(a.coord, order, pos, n, r0 + tid);
     int jc[RJ];
     NodeRec rj[RJ];
+    if (MODE == TSP_2OPT_BEST && a.recs) {
+        const NodeRec *rec = a.recs + (size_t)tour * n;
+        if (tid < r1 - r0) s_rows[tid] = rec[r0 + tid];
 #pragma unroll
-    for (int k = 0; k < RJ; ++k) {
-        jc[k] = c0 + tid + k * kScanThreads;
-        rj[k] = load_node<WT, INT>(a.coord, order, pos, n, min(jc[k], n - 1));
-        if (jc[k] >= n) jc[k] = -1;  // never > i
+        for (int k = 0; k < RJ; ++k) {
+            jc[k] = c0 + tid + k * kScanThreads;
+            rj[k] = rec[min(jc[k], n - 1)];
+            if (jc[k] >= n) jc[k] = -1;  // never > i
+        }
+    } else {
+        if (tid < r1 - r0) s_rows[tid] = load_node<WT, INT>(a.coord, order, pos, n, r0 + tid);
+#pragma unroll
+        for (int k = 0; k < RJ; ++k) {
+            jc[k] = c0 + tid + k * kScanThreads;
+            rj[k] = load_node<WT, INT>(a.coord, order, pos, n, min(jc[k], n - 1));
+            if (jc[k] >= n) jc[k] = -1;  // never > i
+        }
     }
     __syncthreads();
     TSP_STAMP(1);
@@ -422,20 +452,29 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
         for (int i = r0; i < r1; ++i) {
             const NodeRec ri = s_rows[i - r0];
             const double row_bias = ri.ds + a.margin;
+            const double row_t = ri.ds + bd + a.prune;   // a stale (larger) bd only prunes less
             bool need[RJ];
             bool any = false;
 #pragma unroll
             for (int k = 0; k < RJ; ++k) {
-                const double lower = approx_root_dist<WT>(ri.x, ri.y, rj[k].x, rj[k].y) +
-                                     approx_root_dist<WT>(ri.xs, ri.ys, rj[k].xs, rj[k].ys) - row_bias - rj[k].ds;
-                need[k] = lower < bd;
+                need[k] = new_edge_can_improve<WT>(ri.x, ri.y, rj[k].x, rj[k].y, row_t + rj[k].ds);
                 any = any || need[k];
             }
             if (any) {
+                bool any2 = false;
 #pragma unroll
                 for (int k = 0; k < RJ; ++k) {
-                    const double delta = pair_delta<WT, INT>(ri, rj[k]);
-                    if (need[k] && delta < bd) { bd = delta; bi = i; bj = jc[k]; }
+                    const double lower = approx_root_dist<WT>(ri.x, ri.y, rj[k].x, rj[k].y) +
+                                         approx_root_dist<WT>(ri.xs, ri.ys, rj[k].xs, rj[k].ys) - row_bias - rj[k].ds;
+                    need[k] = need[k] & (lower < bd);
+                    any2 = any2 || need[k];
+                }
+                if (any2) {
+#pragma unroll
+                    for (int k = 0; k < RJ; ++k) {
+                        const double delta = pair_delta<WT, INT>(ri, rj[k]);
+                        if (need[k] && delta < bd) { bd = delta; bi = i; bj = jc[k]; }
+                    }
                 }
             }
         }
@@ -465,11 +504,23 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
                     n_eval += ok[k] ? 1 : 0;
                 }
                 if constexpr (FILTER) {
-                    // a pair whose raw-root delta cannot get below the bound is not evaluated exactly
+                    // the new edge alone must be short enough to pay for the two removed edges
                     const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
-                    ok[k] = ok[k] & (pair_delta_approx<WT>(ri, rj[k]) - a.margin < bound);   // '&': no branch
+                    ok[k] = ok[k] & new_edge_can_improve<WT>(ri.x, ri.y, rj[k].x, rj[k].y, bound + ri.ds + rj[k].ds + a.prune);
                 }
                 any_ok = any_ok || ok[k];
+            }
+            if constexpr (FILTER) {
+                if (any_ok) {
+                    // survivors: a pair whose raw-root delta cannot get below the bound is not evaluated exactly
+                    any_ok = false;
+                    const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
+#pragma unroll
+                    for (int k = 0; k < RJ; ++k) {
+                        ok[k] = ok[k] & (pair_delta_approx<WT>(ri, rj[k]) - a.margin < bound);
+                        any_ok = any_ok || ok[k];
+                    }
+                }
             }
             if (!FILTER || any_ok) {
 #pragma unroll
@@ -604,6 +655,8 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.row_tickets = t->d_row_ticket; a.row_slots = t->d_row_slot; a.row_evals = t->d_row_evals;
     a.max_tile_rows = t->max_tile_rows;
     a.tabu = tabu ? tabu->d_stamp : nullptr;
+    // materialising the records costs a launch: worth it once a sweep has thousands of tiles
+    a.recs = (mode == TSP_2OPT_BEST && t->use_recs && t->n >= 4096) ? t->d_rec : nullptr;
     a.partial_per_tour = t->partial_per_tour;
     a.n = t->n;
     a.rows_per_block = mode == TSP_2OPT_BEST ? t->best_rows_per_block : t->first_rows_per_block;
@@ -612,6 +665,7 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.count_evals = t->count_evals;
     a.iter = iter; a.tenure = tenure;
     a.margin = t->inst->filter_margin;
+    a.prune = t->inst->prune_margin;
     return a;
 }
 
@@ -621,6 +675,9 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
     StepArgs a = make_args(t, mode, tabu, iter, tenure);
     if (mode == TSP_2OPT_BEST) {
         const dim3 g = scan_grid<TSP_2OPT_BEST>(t);
+        if (a.recs)
+            hipLaunchKernelGGL((k_recs<WT, INT>), dim3((t->n + kScanThreads - 1) / kScanThreads, t->B), dim3(kScanThreads), 0, s,
+                               t->inst->d_coord, t->d_order, t->d_pos, t->d_state, t->d_rec, t->n);
         if (tabu)
             hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, true>), g, dim3(kScanThreads), 0, s, a);
         else
@@ -787,6 +844,8 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipMalloc(&t->d_partial, (size_t)B * t->partial_per_tour * sizeof(Partial)));
     TSP_HIP_TRY(hipMalloc(&t->d_slot_evals, (size_t)B * t->partial_per_tour * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_ticket, (size_t)B * sizeof(int)));
+    t->use_recs = env_int("TSP_BEST_RECS", 1);
+    TSP_HIP_TRY(hipMalloc(&t->d_rec, bn * sizeof(NodeRec)));
     t->max_tile_rows = std::max((int)gb.y, (int)gf.y);
     TSP_HIP_TRY(hipMalloc(&t->d_row_ticket, (size_t)B * t->max_tile_rows * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_row_evals, (size_t)B * t->max_tile_rows * sizeof(int)));
@@ -801,7 +860,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipSetDevice(t->inst->ctx->device);
     (void)hipStreamSynchronize(t->inst->ctx->stream);
     (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
-    (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket);
+    (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);

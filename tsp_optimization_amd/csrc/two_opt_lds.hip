@@ -33,7 +33,7 @@ template <int WT, bool INT, int MODE>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
-                                                             int rmax, int count_evals, int max_iters, double margin) {
+                                                             int rmax, int count_evals, int max_iters, double margin, double prune) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
     double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
@@ -91,8 +91,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                         const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
                         // a lane's keys are not visited in increasing order here, so BEST must keep ties
                         // (an equal delta with a smaller key wins): skip only when provably greater
-                        const double lower = pair_delta_approx<WT>(ri, rj) - margin;
-                        ok = ok && (MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound);
+                        // (the new-edge bound is written with its margin doubled so that "<" also keeps ties)
+                        ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + 2.0 * prune);
+                        if (ok) {
+                            const double lower = pair_delta_approx<WT>(ri, rj) - margin;
+                            ok = MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound;
+                        }
                     }
                     if (ok) {
                         const double delta = pair_delta<WT, INT>(ri, rj);
@@ -225,13 +229,13 @@ hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_it
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin);
+                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
     } else {
         auto k = k_lds_two_opt<WT, INT, TSP_2OPT_BEST>;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin);
+                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
     }
     return hipGetLastError();
 }
