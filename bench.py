@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip time-to-local-optimum runs")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the bounds-switched-off sweeps (they run the same kernel symbol: keep profiles clean)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,7 +211,8 @@ def main():
         # transparency: the same sweep with the new-edge bound off (every pair gets both raw roots) and with
         # both bounds off (every pair gets the exact delta), on a fresh copy of the same start tour
         variants = {}
-        for label, env in (("no_new_edge_bound", {"TSP_NO_PRUNE": "1"}), ("every_pair_exact", {"TSP_NO_FILTER": "1"})):
+        for label, env in (() if (args.no_variants or args.no_extras) else
+                           (("no_new_edge_bound", {"TSP_NO_PRUNE": "1"}), ("every_pair_exact", {"TSP_NO_FILTER": "1"}))):
             os.environ.update(env)
             inst_v = E.Instance(ctx, xy, wt, 1)
             for k in env:
@@ -221,7 +224,10 @@ def main():
             tours_v.close()
             inst_v.close()
         out["roofline"] = {
-            "kernel": "tsp::k_step<EUC_2D integer-coordinate variant, BEST, RJ=2> (one sweep + move, n=10000)",
+            "kernel": "tsp::k_step<EUC_2D integer-coordinate variant, BEST, RJ=2> (one sweep + move, n=10000), "
+                      "preceded in every launch by tsp::k_recs (per-node records of the current tour); kernel_ms "
+                      "is the HIP-event time of the pair, back to back (rocprof, profiles/r01_kernel_stats.csv: "
+                      "k_step 37.4 us + k_recs 4.9 us)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": ms, "evals_per_launch": evals_per_launch,
@@ -234,7 +240,7 @@ def main():
                     "`variants` gives the same sweep with them switched off",
             "variants": variants,
             "valu": {"measured": "profiles/r01_pmc_sq_wave_counters.json",
-                     "note": "rocprofv3 SQ counters of this kernel: ~16 VALU wave-instructions per wave of 64 "
+                     "note": "rocprofv3 SQ counters of this kernel: ~15 VALU wave-instructions per wave of 64 "
                              "evaluations (common path: 2 sub, mul, fma, add, mul, 2 compares), SQ_ACTIVE_INST_VALU "
                              "~ 50-65 % of the launch's SIMD-cycles; the rest of a wave's life is the synchronised "
                              "tile prologue / epilogue phases"},
