@@ -1,0 +1,127 @@
+"""GPU parity of the sorted best-improvement sweep (k_recs_sorted + k_sweep, two_opt_grid.hip).
+
+By default the engine uses it for n >= 4096, where the CPU oracle needs minutes per descent; these tests set
+TSP_SORTED_MIN_N=0 so that the same kernels run on the small instances the oracle finishes in seconds, and check
+tours, costs and counters against alg_2opt_tabu's restatement (tabusearch.c:107-178).  At full size the sorted
+and the tiled sweep are run against each other (they must agree move for move)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import golden, load_instance, rand_instance, random_tour
+
+pytestmark = pytest.mark.gpu
+
+APB = golden("survey_appendix_b.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from tsp_optimization_amd import engine as E
+    assert E.device_count() >= 1, "no HIP device visible: the product path has no CPU fallback"
+    return E
+
+
+@pytest.fixture(scope="module")
+def ctx(eng):
+    c = eng.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture()
+def sorted_always(monkeypatch):
+    monkeypatch.setenv("TSP_SORTED_MIN_N", "0")
+
+
+def _check_best(eng, inst, xy, wt, succ0, obj0, integer_cost=1):
+    rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.BEST, engine=1)   # 1 = GRID
+    _, es, eo, est, _, _ = O.two_opt_best(xy, wt, succ0, integer_cost=integer_cost)
+    assert rc == 0 and O.is_tour(s)
+    assert (s == es).all(), "final tour differs from the oracle's"
+    assert o == eo
+    assert (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == \
+        (est["sweeps"], est["evals"], est["moves"], est["reversed"])
+    return o, st
+
+
+@pytest.mark.parametrize("name", ["berlin52", "pr299", "att532", "rand1000"])
+def test_sorted_sweep_matches_survey_counters(eng, ctx, sorted_always, name):
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    o, st = _check_best(eng, inst, xy, wt, succ0, obj0)
+    inst.close()
+    e = APB[name]["best"]
+    assert (o, st["sweeps"], st["evals"], st["moves"]) == (e["cost"], e["sw"], e["ev"], e["mv"])
+
+
+@pytest.mark.parametrize("name,ic", [("d493", 0), ("d493", 1), ("dsj1000", 1), ("eil51", 1), ("kroA100", 0)])
+def test_sorted_sweep_other_metrics_and_float_costs(eng, ctx, sorted_always, name, ic):
+    """CEIL_2D (dsj1000), non-integer coordinates (d493), --fcost double costs: the order of the sums matters."""
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, ic)
+    _, succ0, obj0 = O.greedy(xy, wt, integer_cost=ic)
+    _check_best(eng, inst, xy, wt, succ0, obj0, integer_cost=ic)
+    inst.close()
+
+
+@pytest.mark.parametrize("n", [5, 63, 64, 65, 128, 129, 200, 449])
+def test_sorted_sweep_random_tours_and_group_boundaries(eng, ctx, sorted_always, n):
+    rng = np.random.default_rng(n)
+    xy = rng.integers(0, 3000, size=(n, 2)).astype(np.float64)
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    succ0 = random_tour(n, rng)
+    _check_best(eng, inst, xy, O.EUC_2D, succ0, O.succ_cost(xy, O.EUC_2D, succ0))
+    inst.close()
+
+
+def test_sorted_sweep_duplicate_points_and_tied_deltas(eng, ctx, sorted_always):
+    rng = np.random.default_rng(11)
+    xy = rng.integers(0, 12, size=(300, 2)).astype(np.float64)   # coincident nodes, many equal deltas
+    for wt in (O.EUC_2D, O.ATT, O.CEIL_2D):
+        inst = eng.Instance(ctx, xy, wt, 1)
+        succ0 = random_tour(300, rng)
+        _check_best(eng, inst, xy, wt, succ0, O.succ_cost(xy, wt, succ0))
+        inst.close()
+
+
+def test_sorted_sweep_batch_of_tours(eng, ctx, sorted_always):
+    xy, wt = load_instance("pr299")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    n = len(xy)
+    rng = np.random.default_rng(3)
+    succ0 = np.stack([random_tour(n, rng) for _ in range(4)])
+    obj0 = np.array([O.succ_cost(xy, wt, s) for s in succ0])
+    rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.BEST, engine=1)
+    for b in range(4):
+        _, es, eo, est, _, _ = O.two_opt_best(xy, wt, succ0[b])
+        assert (s[b] == es).all() and o[b] == eo
+        assert (st[b]["sweeps"], st[b]["evals"], st[b]["moves"]) == (est["sweeps"], est["evals"], est["moves"])
+    inst.close()
+
+
+@pytest.mark.parametrize("name,steps", [("rand10000", 300), ("rand5000", 400), ("att532x", 0)])
+def test_sorted_and_tiled_sweeps_agree_move_for_move(eng, ctx, monkeypatch, name, steps):
+    """Full size: the same descent through k_sweep and through the tiled k_step (every pair visited)."""
+    if name == "att532x":
+        xy, wt = load_instance("att532")
+        steps = 99
+    else:
+        xy, wt = load_instance(name)
+    out = []
+    for min_n in ("0", "1000000000"):
+        monkeypatch.setenv("TSP_SORTED_MIN_N", min_n)
+        inst = eng.Instance(ctx, xy, wt, 1)
+        succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+        tours = eng.Tours(inst, 1)
+        tours.upload(succ[0], obj[0])
+        tours.run(eng.BEST, max_steps=steps)
+        s, o, st = tours.download()
+        out.append((s.copy(), st[0]))
+        tours.close()
+        inst.close()
+    assert (out[0][0] == out[1][0]).all()
+    keys = ("sweeps", "evals", "moves", "reversed", "pairs_scanned", "steps")
+    assert [out[0][1][k] for k in keys] == [out[1][1][k] for k in keys]
+    assert out[0][1]["moves"] >= min(steps, 90)

@@ -31,3 +31,15 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         print('  %-28s %7.2f us' % (names[k - 1], buf[k] / 100.0)); tot += buf[k] / 100.0
     print('  %-28s %7.2f us' % ('sum (last block lifetime)', tot))
     print('  shader clock during row loops: %.0f MHz; row-loop block-us total %.0f (=> per step %.1f block-us)' % (buf[15], buf[14], buf[14] / max(n, 1) if False else buf[14] / max(st['steps'], 1)))
+
+    if nm == 'BEST' and hasattr(L, 'tsp_dev_debug_sweep'):
+        c = (C.c_ulonglong * 8192)()
+        L.tsp_dev_debug_sweep(c)
+        a = np.array(c[:], dtype=np.float64).reshape(1024, 8)
+        a = a[a[:, 0] > 0]
+        m = lambda k: ((a[:, k] / a[:, 0]).mean() / 100, (a[:, k] / a[:, 0]).max() / 100)
+        print('  k_sweep blocks %d: kept/block mean %.2f' % (len(a), (a[:, 1] / a[:, 0]).mean()))
+        for k, nm2 in ((2, 'start->tests done'), (3, 'tests->staged+barrier'), (4, 'pair loop (wave 0)'), (5, 'barrier after loop')):
+            print('    %-24s mean %.2f us, slowest block %.2f us' % ((nm2,) + m(k)))
+        print('    last launch: block start skew %.2f us, span first start -> last loop end %.2f us'
+              % ((a[:, 6].max() - a[:, 6].min()) / 100, (a[:, 7].max() - a[:, 6].min()) / 100))

@@ -13,6 +13,7 @@ python3 - <<PY
 import json
 d=json.load(open("$R/gpurun_out/${TAG}.json"))
 for k,v in d.items():
-    if "k_step<6, true, 1" in k:
+    if "k_step<6, true, 1" in k or "k_sweep" in k or "k_move_recs" in k:
+        print(k)
         for c,x in sorted(v.items()): print("%-24s %16.1f" % (c, x["mean"]))
 PY

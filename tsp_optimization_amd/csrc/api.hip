@@ -36,6 +36,19 @@ tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc
 }
 
 namespace {
+// Rank of cell (x, y) of a 65536 x 65536 grid along the Hilbert curve (the classic xy -> d walk).
+unsigned hilbert_rank16(unsigned x, unsigned y) {
+    unsigned d = 0;
+    for (unsigned s = 1u << 15; s > 0; s >>= 1) {
+        const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = s - 1 - x; y = s - 1 - y; }
+            const unsigned t = x; x = y; y = t;
+        }
+    }
+    return d;
+}
 double wall_s() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -181,6 +194,10 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
             inst->prune_margin = 1e300;
             if (sqrt_metric && !(nop && *nop == '1') && !(nof && *nof == '1') && span < 1e100)
                 inst->prune_margin = ((inst->integer_cost && inst->wtype == TSP_EUC_2D) ? 0.5 : 0.0) + 1e-6 + span * 0x1p-36;
+            // both new edges: nint() shortens each by at most 1/2; slack doubled so that '<' keeps ties.  The test
+            // multiplies squared distances: only for spans whose fourth power is far from overflow.
+            if (inst->prune_margin < 1e299 && span < 1e60)
+                inst->sum_margin = ((inst->integer_cost && inst->wtype == TSP_EUC_2D) ? 1.0 : 0.0) + 2e-6 + span * 0x1p-34;
         }
         const char *off = getenv("TSP_NO_ICOORD");
         if (all_int && span < TSP_ICOORD_MAX_DIST && !(off && *off == '1')) {
@@ -196,6 +213,38 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
     }
     TSP_HIP_TRY(hipMalloc(&inst->d_coord, sizeof(double2) * (size_t)n));
     TSP_HIP_TRY(hipMemcpyAsync(inst->d_coord, c.data(), sizeof(double2) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    if (inst->sum_margin < 1e299) {
+        // Sorted sweep: rank the nodes along a Hilbert curve; 64 consecutive ranks form a group whose bounding
+        // box lets whole 64 x 64 blocks of pairs be decided by the new-edge bound at once (two_opt_grid.hip).
+        const int ng = (n + 63) / 64, n_slots = (ng + 1) * 64;
+        double lox = xy[0], hix = xy[0], loy = xy[1], hiy = xy[1];
+        for (int v = 0; v < n; ++v) {
+            lox = std::min(lox, xy[2 * v]); hix = std::max(hix, xy[2 * v]);
+            loy = std::min(loy, xy[2 * v + 1]); hiy = std::max(hiy, xy[2 * v + 1]);
+        }
+        const double sx = hix > lox ? 65535.0 / (hix - lox) : 0.0, sy = hiy > loy ? 65535.0 / (hiy - loy) : 0.0;
+        std::vector<std::pair<unsigned, int>> key((size_t)n);
+        for (int v = 0; v < n; ++v)
+            key[v] = {hilbert_rank16((unsigned)((xy[2 * v] - lox) * sx), (unsigned)((xy[2 * v + 1] - loy) * sy)), v};
+        std::sort(key.begin(), key.end());
+        std::vector<int> sperm((size_t)n_slots, -1);
+        std::vector<double4> gbox((size_t)ng + 1);
+        for (int g = 0; g <= ng; ++g) gbox[g] = make_double4(1e30, 1e30, 1e30, 1e30);   // {min x, max x, min y, max y}
+        for (int k = 0; k < n; ++k) {
+            const int v = key[k].second, g = k / 64;
+            sperm[k] = v;
+            double4 &b = gbox[g];
+            if ((k & 63) == 0) b = make_double4(xy[2 * v], xy[2 * v], xy[2 * v + 1], xy[2 * v + 1]);
+            b.x = std::min(b.x, xy[2 * v]); b.y = std::max(b.y, xy[2 * v]);
+            b.z = std::min(b.z, xy[2 * v + 1]); b.w = std::max(b.w, xy[2 * v + 1]);
+        }
+        inst->ng = ng; inst->n_slots = n_slots;
+        TSP_HIP_TRY(hipMalloc(&inst->d_sperm, sizeof(int) * (size_t)n_slots));
+        TSP_HIP_TRY(hipMalloc(&inst->d_gbox, sizeof(double4) * ((size_t)ng + 1)));
+        TSP_HIP_TRY(hipMemcpyAsync(inst->d_sperm, sperm.data(), sizeof(int) * (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));
+        TSP_HIP_TRY(hipMemcpyAsync(inst->d_gbox, gbox.data(), sizeof(double4) * ((size_t)ng + 1), hipMemcpyHostToDevice, ctx->stream));
+        TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the staging vectors die with this scope
+    }
     TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out = inst;
     return TSP_OK;
@@ -207,7 +256,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     (void)hipStreamSynchronize(inst->ctx->stream);
     if (inst->scratch1) tsp_dev_tours_destroy(inst->scratch1);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
-    (void)hipFree(inst->d_coord);
+    (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox);
     delete inst;
 }
 

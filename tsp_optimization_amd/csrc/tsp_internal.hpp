@@ -32,6 +32,9 @@ struct alignas(16) TourState {
     double obj;       // FIRST: running obj_best (+= delta); BEST: recomputed cost once done
     double seen_cost; // FIRST: best_cost of heuristics.c:442,492,495
     long long sweeps, evals, moves, reversed, pairs_scanned, steps;
+    // sorted sweep: order/pos exist twice; `parity` says which copy holds the tour, `pending` that the move
+    // (reverse positions mv_pa+1 .. mv_pb) chosen by the last sweep has not been carried out yet
+    int parity, pending, mv_pa, mv_pb;
 };
 
 constexpr int kScanThreads = 256;
@@ -59,8 +62,15 @@ struct tsp_dev_inst {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // reusable timing events
     double filter_margin = 1e300; // root filter margin of the 2-opt scans (tsp_dist.hpp); 1e300 = off
     double prune_margin = 1e300;  // new-edge bound margin (tsp_dist.hpp); 1e300 = off
+    double sum_margin = 1e300;    // sorted sweep, both new edges: |ab| + |a1 b1| < bound + d(a,a1) + d(b,b1) + this
     int integer_cost = 1;
     double2 *d_coord = nullptr; // n x (x,y) or (lat,lon) for GEO
+    // Sorted sweep (sqrt metrics): nodes ranked along a Hilbert curve, 64 consecutive ranks = one group.
+    // d_sperm[slot] = node (or -1 for padding), n_slots = (ng + 1) * 64 (one extra all-padding group);
+    // d_gbox[g] = {min x, max x, min y, max y} of group g's nodes (the padding group sits far away).
+    int *d_sperm = nullptr;
+    double4 *d_gbox = nullptr;
+    int ng = 0, n_slots = 0;
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
 };
 
@@ -77,10 +87,15 @@ struct tsp_dev_tours {
     // device
     int *d_order = nullptr;          // B x n : node at tour position p
     int *d_pos = nullptr;            // B x n : position of node v
+    int *d_order2 = nullptr, *d_pos2 = nullptr;   // second copies (sorted sweep: moves are applied out of place)
     tsp::TourState *d_state = nullptr;
     tsp::Partial *d_partial = nullptr;
     size_t partial_per_tour = 0;
-    tsp::NodeRec *d_rec = nullptr;   // B x n node records, rebuilt before every BEST step (k_recs)
+    tsp::NodeRec *d_rec = nullptr;   // B x max(n, n_slots) node records, rebuilt before every BEST step (k_recs*)
+    double *d_gmax = nullptr;        // B x (ng + 1): longest tour edge leaving a node of the group (sorted sweep)
+    unsigned long long *d_gbest = nullptr;  // B: best delta any block has found so far in the running sweep (bits)
+    int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep
+    int sweep_blocks = 512;          // k_sweep blocks per tour
     int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
     int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)
     tsp::Partial *d_row_slot = nullptr;

@@ -94,7 +94,7 @@ struct alignas(16) NodeRec {
     double xs, ys;  // succ(node)
     double ds;      // calc_dist(node, succ(node))
     int succ;
-    int pad;
+    int id;         // the node itself (records stored out of node order carry it: sorted sweep)
 };
 static_assert(sizeof(NodeRec) == 48, "NodeRec must be 48 bytes");
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ NodeRec load_node(const COORD *coord, const ORD *orde
     NodeRec r;
     r.x = c.x; r.y = c.y; r.xs = cs.x; r.ys = cs.y;
     r.ds = dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
-    r.succ = s; r.pad = 0;
+    r.succ = s; r.id = v;
     return r;
 }
 

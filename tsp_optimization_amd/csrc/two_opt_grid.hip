@@ -34,6 +34,8 @@ constexpr int kMaxRowsPerBlock = 256;
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_stamp_sum[16];
 __device__ unsigned long long g_stamp_n;
+__device__ unsigned long long g_blk[1024][8];   // per k_sweep block (plain accumulation): launches, kept, ticks tests->staged, ticks tests->loop end
+__device__ unsigned long long g_sw_cnt[8];   // k_sweep: survivors kept, max kept, row quads, with tier 1, with exact, blocks, loop ticks, max loop ticks
 __device__ unsigned long long g_clk_core, g_clk_real;   // row-loop time of every block: shader cycles vs 100 MHz ticks
 #define TSP_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
 #else
@@ -194,9 +196,16 @@ struct StepArgs {
     int n, rows_per_block, first_min_rows, first_max_rows, count_evals, iter, tenure;
     double margin;     // root filter (tsp_dist.hpp); 1e300 = every pair is evaluated exactly
     double prune;      // new-edge bound margin (tsp_dist.hpp); 1e300 = never prune
+    // sorted sweep (k_sweep): records in Hilbert-rank order, group boxes, per-group longest edge, shared bound
+    double sum_margin; // k_sweep tier 1: rounding of the two new distances + fp slack (doubled: keeps ties)
+    int *orders2, *poss2;  // k_sweep / k_move_recs: the second copy of order/pos (TourState::parity says which is current)
+    const double4 *gbox;
+    const double *gmax;
+    unsigned long long *gbest;
+    int ng, n_slots, flat_slots;
 };
 
-template <int WT, bool INT, int MODE, int RJ, bool TABU>
+template <int WT, bool INT, int MODE, int RJ, bool TABU, bool FLAT = false>
 __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_lo, int row_hi
 #ifdef TSP_STAMPS
                                            , unsigned long long *stamps
@@ -209,6 +218,12 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
     const int tid = threadIdx.x;
     int *order = a.orders + (size_t)tour * n;
     int *pos = a.poss + (size_t)tour * n;
+    int cur_parity = 0;
+    if constexpr (FLAT) {
+        // k_move_recs has just carried the previous step's move out into the other copy: that one is current now
+        cur_parity = st->parity ^ st->pending;
+        if (cur_parity) { order = a.orders2 + (size_t)tour * n; pos = a.poss2 + (size_t)tour * n; }
+    }
     const Partial *part = a.partials + (size_t)tour * a.partial_per_tour;
 
     __shared__ double s_d[kScanThreads / 64];
@@ -216,10 +231,11 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
     __shared__ long long s_ll[kScanThreads / 64];
     __shared__ int s_i32[kScanThreads / 64];
 
-    constexpr bool HIER = MODE == TSP_2OPT_BEST;  // BEST: one pre-reduced candidate per tile row
+    // BEST: one pre-reduced candidate per tile row; FLAT (sorted sweep): one candidate per block, all live
+    constexpr bool HIER = MODE == TSP_2OPT_BEST && !FLAT;
     const int ci = MODE == TSP_2OPT_FIRST ? st->ci : 0, cj = MODE == TSP_2OPT_FIRST ? st->cj : 0;
     const int tile_rows = min((row_hi - row_lo + rpb - 1) / rpb, gy);
-    const int nslots = HIER ? tile_rows : tile_rows * gx;
+    const int nslots = FLAT ? a.flat_slots : (HIER ? tile_rows : tile_rows * gx);
     if constexpr (HIER) part = a.row_slots + (size_t)tour * a.max_tile_rows;
 
     // 1. winner over the blocks that published a candidate (loads batched: they are sc1 loads
@@ -234,7 +250,7 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
         for (int k = 0; k < PU; ++k) {
             const int s = s0 + k * kScanThreads;
             const int by = s / gx, bx = s - by * gx;
-            live[k] = s < nslots && (HIER || bx >= skipped_in_tile_row(row_lo + by * rpb, gx, TJ));
+            live[k] = s < nslots && (HIER || FLAT || bx >= skipped_in_tile_row(row_lo + by * rpb, gx, TJ));
             pd[k] = 0.0; pi[k] = -1; pj[k] = -1;
             if (live[k]) read_partial(part + s, pd[k], pi[k], pj[k]);
         }
@@ -284,8 +300,8 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
 
     // 3. the move: reverse positions pa+1 .. pb (cyclic)
     int L = 0;
-    if (found) {
-        L = pb - pa; if (L < 0) L += n;
+    if (found) { L = pb - pa; if (L < 0) L += n; }
+    if (found && !FLAT) {   // FLAT: the move is left to the next launch of k_move_recs (all blocks, not one)
         const int half = L >> 1;
         constexpr int U = 4;
         for (int t0 = tid; t0 < half; t0 += U * kScanThreads) {
@@ -343,7 +359,7 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
         for (int k = tid; k < tile_rows; k += kScanThreads)
             __hip_atomic_store((gi32 *)(a.row_tickets + (size_t)tour * a.max_tile_rows + k), 0, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    } else if constexpr (!FLAT) {
         next_active = count_active_blocks(next_lo, next_hi, rpb, gx, gy, TJ, s_i32);
     }
 
@@ -364,7 +380,8 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
         }
         st->obj = obj;
         st->done = done;
-        if constexpr (!HIER)
+        if constexpr (FLAT) { st->parity = cur_parity; st->pending = found ? 1 : 0; st->mv_pa = pa; st->mv_pb = pb; }
+        if constexpr (!HIER && !FLAT)
             __hip_atomic_store((gi32 *)(a.tickets + tour), done ? 0 : next_active, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
 #ifdef TSP_STAMPS
@@ -614,6 +631,363 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
 #endif
 }
 
+// ---- sorted sweep (BEST, sqrt metrics) ------------------------------------------------------------------------
+// The new-edge bound says a pair (a, b) can only beat `bound` if |ab| < bound + d(a,succ a) + d(b,succ b) + margin.
+// With the nodes ranked along a Hilbert curve, 64 consecutive ranks form a compact group, and the same bound
+// with the groups' bounding boxes and their longest tour edges decides 64 x 64 pairs at once: on a constructed
+// tour 80-95 % of the group pairs of a sweep never reach the pair loop.  Nothing about the result changes:
+// every decision the reference takes (strict '<', first pair in (i<j) order among equal deltas) is taken on
+// exact values with the nodes' own ids; the order in which pairs are visited is free in a best-improvement sweep.
+//
+// The move a sweep chose is carried out by the NEXT launch, by all of its blocks: order/pos exist twice, the
+// reversal of positions pa+1 .. pb is a gather from the current copy into the other one
+//     new_order[p] = old_order[mirror(p)],  mirror(p) = pa + 1 + (L - 1 - t) for t = (p - pa - 1) mod n < L, else p
+// and the records of the next sweep are built from the same closed form, so nothing waits for the copy.
+struct MoveView {
+    const int *order, *pos;   // the current copy
+    int n, pa1, L;            // pending reversal: positions pa1 .. pa1 + L - 1 (cyclic); L == 0: none
+    __device__ __forceinline__ int mirror(int p) const {
+        int t = p - pa1; if (t < 0) t += n;
+        if (t >= L) return p;
+        int q = pa1 + (L - 1 - t); if (q >= n) q -= n;
+        return q;
+    }
+    __device__ __forceinline__ int node_at(int p) const { return order[mirror(p)]; }   // node at new position p
+    __device__ __forceinline__ int pos_of(int v) const { return mirror(pos[v]); }       // the mirror is an involution
+};
+
+__device__ __forceinline__ MoveView move_view(const TourState *st, const int *o1, const int *p1, const int *o2,
+                                              const int *p2, int n) {
+    MoveView m;
+    const bool second = st->parity != 0;
+    m.order = second ? o2 : o1; m.pos = second ? p2 : p1; m.n = n;
+    m.L = 0; m.pa1 = 0;
+    if (st->pending) {
+        int L = st->mv_pb - st->mv_pa; if (L < 0) L += n;
+        m.L = L; m.pa1 = st->mv_pa + 1 == n ? 0 : st->mv_pa + 1;
+    }
+    return m;
+}
+
+// k_move_recs: (1) the pending move, out of place; (2) the record of every node in rank order for the sweep that
+// follows, on the tour AFTER that move; (3) each group's longest edge.  Writes no control state: the sweep's last
+// block notes that the other copy is current from now on (apply_step, FLAT).
+template <int WT, bool INT>
+__global__ __launch_bounds__(kScanThreads) void k_move_recs(const double2 *__restrict__ coord, int *orders, int *poss,
+                                                            int *orders2, int *poss2, const TourState *__restrict__ states,
+                                                            const int *__restrict__ sperm, NodeRec *__restrict__ recs,
+                                                            double *__restrict__ gmax, int n, int ng, int n_slots) {
+    const int tour = blockIdx.y;
+    const TourState *st = states + tour;
+    if (st->done) return;
+    const size_t base = (size_t)tour * n;
+    const MoveView mv = move_view(st, orders + base, poss + base, orders2 + base, poss2 + base, n);
+    const int k = blockIdx.x * kScanThreads + threadIdx.x;
+    if (mv.L > 0 && k < n) {   // new position k
+        int *o_new = (st->parity ? orders : orders2) + base, *p_new = (st->parity ? poss : poss2) + base;
+        const int v = mv.node_at(k);
+        o_new[k] = v;
+        p_new[v] = k;
+    }
+    if (k >= n_slots) return;
+    const int v = sperm[k];
+    NodeRec r;
+    if (v >= 0) {
+        int ps = mv.pos_of(v) + 1; if (ps == n) ps = 0;
+        const int sc = mv.node_at(ps);
+        const double2 c = coord[v], cs = coord[sc];
+        r.x = c.x; r.y = c.y; r.xs = cs.x; r.ys = cs.y;
+        r.ds = dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
+        r.succ = sc; r.id = v;
+    } else {   // padding: far away from everything, never passes the new-edge test
+        r.x = r.y = r.xs = r.ys = 1e30; r.ds = 0.0; r.succ = -1; r.id = -1;
+    }
+    recs[(size_t)tour * n_slots + k] = r;
+    double m = r.ds;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) gmax[(size_t)tour * (ng + 1) + (k >> 6)] = m;
+}
+
+// End of a run through the sorted sweep: bring the tour back into the first copy of order/pos, where every other
+// path expects it.  Three tiny launches, each reading a control block nobody writes meanwhile.
+__global__ void k_flush_move(int *orders, int *poss, int *orders2, int *poss2, const TourState *__restrict__ states, int n) {
+    const int tour = blockIdx.y;
+    const TourState *st = states + tour;
+    if (!st->pending) return;
+    const size_t base = (size_t)tour * n;
+    const MoveView mv = move_view(st, orders + base, poss + base, orders2 + base, poss2 + base, n);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int *o_new = (st->parity ? orders : orders2) + base, *p_new = (st->parity ? poss : poss2) + base;
+    const int v = mv.node_at(k);
+    o_new[k] = v;
+    p_new[v] = k;
+}
+__global__ void k_flush_copy(int *orders, int *poss, const int *orders2, const int *poss2,
+                             const TourState *__restrict__ states, int n) {
+    const int tour = blockIdx.y;
+    const TourState *st = states + tour;
+    if ((st->parity ^ st->pending) == 0) return;   // the tour already sits in the first copy
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const size_t base = (size_t)tour * n;
+    orders[base + k] = orders2[base + k];
+    poss[base + k] = poss2[base + k];
+}
+__global__ void k_flush_state(TourState *states, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { states[b].parity = 0; states[b].pending = 0; }
+}
+
+// Non-positive deltas order like their bit patterns read as unsigned (more negative = larger).
+__device__ __forceinline__ double gbest_load(unsigned long long *g) {
+    return __longlong_as_double((long long)__hip_atomic_load((gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Group pair number t (0 <= t < ng (ng + 1) / 2, rows first) -> (row group r, column group c >= r).
+__device__ __forceinline__ void group_pair(int t, int ng, int &r, int &c) {
+    const double b = 2.0 * ng + 1.0;
+    int rr = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    rr = max(0, min(rr, ng - 1));
+    // first pair of row group r: off(r) = r ng - r (r - 1) / 2
+    while (rr > 0 && (long long)rr * ng - (long long)rr * (rr - 1) / 2 > t) --rr;
+    while ((long long)(rr + 1) * ng - (long long)(rr + 1) * rr / 2 <= t) ++rr;
+    r = rr;
+    c = rr + (int)(t - ((long long)rr * ng - (long long)rr * (rr - 1) / 2));
+}
+
+constexpr int kSweepCluster = 8;      // blocks that test the same group pairs and deal the survivors among themselves
+constexpr int kSweepRows = 32;        // rows of one unit of wave work
+constexpr int kSweepStage = 8;        // group pairs whose records a block holds in LDS at a time (6 KB each)
+constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are processed in further passes)
+
+// k_sweep.  Blocks come in clusters of kSweepCluster.  Cluster q tests the group pairs t = q, q + Q, q + 2Q, ...
+// (row group r against column group c >= r; c == r: the pairs inside the group) with the groups' boxes and longest
+// edges -- one test per thread and round, every block of the cluster the same tests, so that all of them see the
+// same ordered survivor list and block j keeps entries j, j + C, ...: the survivors of a sweep are very unevenly
+// spread over the row groups (a group that holds one long edge survives against everything), the strided sample
+// plus the deal spreads them evenly over the chip without a queue or a second launch.
+// A wave then takes half a surviving group pair at a time: rows 32h .. 32h+31 of r against one column of c per
+// lane.  The 32 row records are staged in the wave's own LDS strip and read back as wave-uniform broadcasts; the
+// waves of a block share nothing until the block's arg-min.  Rows go four at a time so that the LDS reads and the
+// fp64 chains of different rows overlap.
+template <int WT, bool INT>
+__global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
+    constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
+    constexpr int NW = kScanThreads / 64;
+#ifdef TSP_STAMPS
+    __shared__ unsigned long long stamps[16];
+#endif
+    TSP_STAMP(0);
+#ifdef TSP_STAMPS
+    const unsigned long long bt0 = wall_clock64();
+    unsigned long long bt3 = 0;
+#endif
+    const int tour = blockIdx.z;
+    const TourState *st = a.states + tour;
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ng = a.ng;
+    const NodeRec *rec = a.recs + (size_t)tour * a.n_slots;
+    const double *gmax = a.gmax + (size_t)tour * (ng + 1);
+    const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
+    const int Q = (int)gridDim.x / kSweepCluster, q = (int)blockIdx.x / kSweepCluster, j = (int)blockIdx.x % kSweepCluster;
+    const int npairs = ng * (ng + 1) / 2;
+    const int ntests = (npairs + Q - 1) / Q;   // stride blocks of group pairs; the last one may be partial
+
+    __shared__ NodeRec s_stage[kSweepStage][128];   // per staged group pair: 64 row records, 64 column records
+    __shared__ double4 s_cbox[kSweepStage];
+    __shared__ double s_cgmax[kSweepStage];
+    __shared__ int s_list[kSweepListCap];   // r << 16 | c
+    __shared__ int s_wcount[NW];
+    double bd = 0.0;
+    u64 key = kNoKey;
+
+    int m0 = 0;
+    int seen = 0;          // survivors of the cluster so far (same in every block of the cluster)
+    while (m0 < ntests) {
+        // ---- tests: rounds of one group pair per thread until the block's list may be full or the pairs run out
+        // (the pass ends on a condition every block of the cluster evaluates alike, or their ranks would part)
+        int kept = 0;      // entries in s_list (same value in every thread)
+        const int seen0 = seen;
+        while (m0 < ntests && (seen - seen0) / kSweepCluster + kScanThreads / kSweepCluster + 2 <= kSweepListCap) {
+            const int m = m0 + tid;
+            bool surv = false;
+            int r = 0, c = 0;
+            if (m < ntests && Q * m + (q + 29 * m) % Q < npairs) {
+                // pair number: stride Q with a rotation per stride block (a plain stride would hand a cluster a
+                // lattice in (r, c) that can sit on the diagonal, where every pair survives)
+                group_pair(Q * m + (q + 29 * m) % Q, ng, r, c);
+                const double4 rb = a.gbox[r], cb = a.gbox[c];
+                const double gx = fmax(0.0, fmax(rb.x - cb.y, cb.x - rb.y)), gy = fmax(0.0, fmax(rb.z - cb.w, cb.z - rb.w));
+                const double T = gmax[r] + gmax[c] + prune2;   // bound 0: nothing is known about this sweep yet
+                surv = gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+            }
+            const unsigned long long bal = __ballot(surv);
+            if (lane == 0) s_wcount[wave] = __popcll(bal);
+            __syncthreads();
+            int before = seen, total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const int cw = s_wcount[w]; before += (w < wave) ? cw : 0; total += cw; }
+            const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));   // place in the cluster's list
+            // entries of this block among ranks [seen, seen + total): those with rank % C == j
+            const int first_mine = seen + ((j - seen % kSweepCluster + kSweepCluster) % kSweepCluster);
+            if (surv && rank % kSweepCluster == j) s_list[kept + (rank - first_mine) / kSweepCluster] = (r << 16) | c;
+            kept += (seen + total > first_mine) ? (seen + total - first_mine + kSweepCluster - 1) / kSweepCluster : 0;
+            seen += total;
+            m0 += kScanThreads;
+            __syncthreads();
+        }
+
+        TSP_STAMP(1);
+#ifdef TSP_STAMPS
+        const unsigned long long lt0 = wall_clock64();
+        if (tid == 0 && blockIdx.x < 1024) { g_blk[blockIdx.x][0] += 1; g_blk[blockIdx.x][1] += kept; g_blk[blockIdx.x][2] += lt0 - bt0; g_blk[blockIdx.x][6] = bt0; }
+#endif
+        // ---- the block's survivors, kSweepStage group pairs at a time: all 128 records of each pair are fetched
+        // by the whole block in one burst (one memory latency per chunk instead of one per unit of wave work),
+        // then every wave takes half a group pair at a time out of LDS
+        for (int e0 = 0; e0 < kept; e0 += kSweepStage) {
+            const int ne = min(kSweepStage, kept - e0);
+            if (tid < ne) {   // the column groups' boxes and longest edges, for the row culling below
+                const int c = s_list[e0 + tid] & 0xffff;
+                s_cbox[tid] = a.gbox[c];
+                s_cgmax[tid] = gmax[c];
+            }
+            {   // a record is three 16-byte pieces; all loads of a thread are issued before its first LDS store
+                constexpr int PER = kSweepStage * 128 * 3 / kScanThreads;
+                const double2 *src = reinterpret_cast<const double2 *>(rec);
+                double2 *dst = reinterpret_cast<double2 *>(&s_stage[0][0]);
+                double2 tmp[PER];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int x = tid + k * kScanThreads;      // piece x of the chunk
+                    const int rcd = x / 3, part = x - rcd * 3;  // record 0 .. ne * 128 - 1
+                    tmp[k] = make_double2(0.0, 0.0);
+                    if (rcd < ne * 128) {
+                        const int e = s_list[e0 + (rcd >> 7)];
+                        const int g = (rcd & 64) ? (e & 0xffff) : (e >> 16);   // 0..63 rows of r, 64..127 columns of c
+                        tmp[k] = src[(g * 64 + (rcd & 63)) * 3 + part];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int x = tid + k * kScanThreads;
+                    if (x < ne * 128 * 3) dst[x] = tmp[k];
+                }
+            }
+            __syncthreads();
+#ifdef TSP_STAMPS
+            if (tid == 0 && blockIdx.x < 1024 && e0 == 0) { bt3 = wall_clock64(); g_blk[blockIdx.x][3] += bt3 - lt0; }
+#endif
+        for (int ht = wave; ht < 2 * ne; ht += NW) {
+            const int e = s_list[e0 + (ht >> 1)];
+            const int r = e >> 16, cgp = e & 0xffff, row0 = (ht & 1) * kSweepRows;
+            const NodeRec *rows = &s_stage[ht >> 1][row0];
+            const NodeRec rj = s_stage[ht >> 1][64 + lane];
+            const double cds = rj.ds + prune2, cds2 = rj.ds + a.sum_margin;
+            double bound = bd;   // the lane's own best so far
+            // Rows that cannot reach the column group's box at all are dropped for the whole wave (one row per
+            // lane, one ballot): about 60 % of the rows of a surviving group pair.  bound = 0 here: the test must
+            // hold for every lane, and a lane that has found nothing yet has no better bound.
+            unsigned alive;
+            {
+                const double4 cb = s_cbox[ht >> 1];
+                const NodeRec &rr = rows[lane & (kSweepRows - 1)];
+                const double gx = fmax(0.0, fmax(cb.x - rr.x, rr.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rr.y, rr.y - cb.w));
+                const double T = rr.ds + s_cgmax[ht >> 1] + prune2;
+                const bool reach = lane < kSweepRows && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+                alive = __builtin_amdgcn_readfirstlane((unsigned)__ballot(reach));
+            }
+            // tiers 1 and 2 for four rows (need[u]: tier 0 could not exclude row idx[u] for this lane)
+            auto rare4 = [&](const int (&idx)[4], const bool (&need)[4]) {
+                // tier 1, both new edges, still without a root: |ab| + |a1 b1| < T2 = bound + d(a,a1) + d(b,b1) +
+                // margin  <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2.  All four rows in straight-line code.
+                bool ok[4];
+                bool any2 = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const NodeRec &ri = rows[idx[u]];
+                    const double dx1 = ri.x - rj.x, dy1 = ri.y - rj.y;
+                    const double dx = ri.xs - rj.xs, dy = ri.ys - rj.ys, T2 = ri.ds + bound + cds2;
+                    const double sc = ATT10 ? 0.1 : 1.0;
+                    const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
+                    const double w = T2 * T2 - p1 - p2;
+                    // one slot pair once (inside a group: row slot below column slot), never adjacent nodes
+                    ok[u] = need[u] && T2 > 0.0 && w > 0.0 && 4.0 * p1 * p2 < w * w &&
+                            (cgp > r || row0 + idx[u] < lane) && ri.id >= 0 && rj.id >= 0 &&
+                            rj.id != ri.succ && rj.succ != ri.id;
+                    any2 = any2 || ok[u];
+                }
+                if (any2) {   // tier 2: the exact delta
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok[u]) {
+                            const NodeRec ri = rows[idx[u]];
+                            const double delta = pair_delta<WT, INT>(ri, rj);
+                            const u64 kk = make_key(min(ri.id, rj.id), max(ri.id, rj.id));
+                            if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) { bd = delta; key = kk; bound = bd; }
+                        }
+                    }
+                }
+            };
+            // four live rows at a time (a short last group repeats its last row: the same pair twice changes nothing)
+            while (alive) {
+                int idx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (alive) { idx[u] = __builtin_ctz(alive); alive &= alive - 1; }
+                    else idx[u] = idx[u > 0 ? u - 1 : 0];
+                }
+                bool need[4];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin
+                    const NodeRec &ri = rows[idx[u]];
+                    const double dx = ri.x - rj.x, dy = ri.y - rj.y, T = ri.ds + bound + cds;
+                    need[u] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);   // T <= 0: never
+                    any = any || need[u];
+                }
+                if (any) rare4(idx, need);
+            }
+        }
+#ifdef TSP_STAMPS
+            const unsigned long long bt4 = wall_clock64();
+#endif
+            __syncthreads();   // the stage (and, after the last chunk, s_list) is rewritten next
+#ifdef TSP_STAMPS
+            if (tid == 0 && blockIdx.x < 1024 && e0 == 0) { const unsigned long long bt5 = wall_clock64(); g_blk[blockIdx.x][4] += bt4 - bt3; g_blk[blockIdx.x][5] += bt5 - bt4; g_blk[blockIdx.x][7] = bt5; }
+#endif
+        }
+    }
+
+    __shared__ double s_d[NW];
+    __shared__ u64 s_k[NW];
+    __shared__ int s_last;
+    TSP_STAMP(2);
+    block_argmin<true>(bd, key, s_d, s_k);
+    TSP_STAMP(3);
+    if (tid == 0) {
+        const size_t slot_idx = (size_t)tour * a.partial_per_tour + blockIdx.x;
+        publish_partial(a.partials + slot_idx, bd, key_i(key), key_j(key));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
+        TSP_STAMP(4);
+        const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old + 1 == (int)gridDim.x);
+        if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    TSP_STAMP(5);
+#ifdef TSP_STAMPS
+    apply_step<WT, INT, TSP_2OPT_BEST, 2, false, true>(a, tour, 0, a.n - 1, stamps);
+#else
+    apply_step<WT, INT, TSP_2OPT_BEST, 2, false, true>(a, tour, 0, a.n - 1);
+#endif
+}
+
 __global__ void k_stamp_scatter(int *__restrict__ stamp, const int *__restrict__ idx, const int *__restrict__ val,
                                 int count) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -648,6 +1022,24 @@ dim3 scan_grid(const tsp_dev_tours *t) {
     return dim3(gx, gy, t->B);
 }
 
+int env_int(const char *name, int dflt);
+
+// BEST sweeps of this handle go through k_recs_sorted + k_sweep (no tabu list, metric with the new-edge bound)
+bool sorted_sweep(const tsp_dev_tours *t) {
+    return t->inst->d_sperm && t->d_gmax && t->d_order2 && t->n >= t->sorted_min_n && t->inst->prune_margin < 1e299 &&
+           t->inst->ng < 65535;   // k_sweep packs (r, c) into one int and counts group pairs in 31 bits
+}
+
+// After sorted sweeps: pending move carried out, tour back in the first copy of order/pos.
+void launch_flush(tsp_dev_tours *t) {
+    if (!t->d_order2) return;
+    hipStream_t s = t->inst->ctx->stream;
+    const dim3 g((t->n + 255) / 256, t->B);
+    hipLaunchKernelGGL(k_flush_move, g, dim3(256), 0, s, t->d_order, t->d_pos, t->d_order2, t->d_pos2, t->d_state, t->n);
+    hipLaunchKernelGGL(k_flush_copy, g, dim3(256), 0, s, t->d_order, t->d_pos, t->d_order2, t->d_pos2, t->d_state, t->n);
+    hipLaunchKernelGGL(k_flush_state, dim3((t->B + 255) / 256), dim3(256), 0, s, t->d_state, t->B);
+}
+
 StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
     StepArgs a;
     a.coord = t->inst->d_coord; a.orders = t->d_order; a.poss = t->d_pos; a.states = t->d_state;
@@ -666,6 +1058,11 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.iter = iter; a.tenure = tenure;
     a.margin = t->inst->filter_margin;
     a.prune = t->inst->prune_margin;
+    a.sum_margin = t->inst->sum_margin;
+    a.orders2 = t->d_order2; a.poss2 = t->d_pos2;
+    a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax; a.gbest = t->d_gbest;
+    a.ng = t->inst->ng; a.n_slots = t->inst->n_slots;
+    a.flat_slots = t->sweep_blocks;
     return a;
 }
 
@@ -673,6 +1070,17 @@ template <int WT, bool INT>
 int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
     hipStream_t s = t->inst->ctx->stream;
     StepArgs a = make_args(t, mode, tabu, iter, tenure);
+    if constexpr (has_root_filter<WT>()) {
+        if (mode == TSP_2OPT_BEST && !tabu && sorted_sweep(t)) {
+            a.recs = t->d_rec;
+            const int ns = t->inst->n_slots;
+            hipLaunchKernelGGL((k_move_recs<WT, INT>), dim3((std::max(ns, t->n) + kScanThreads - 1) / kScanThreads, t->B),
+                               dim3(kScanThreads), 0, s, t->inst->d_coord, t->d_order, t->d_pos, t->d_order2, t->d_pos2,
+                               t->d_state, t->inst->d_sperm, t->d_rec, t->d_gmax, t->n, t->inst->ng, ns);
+            hipLaunchKernelGGL((k_sweep<WT, INT>), dim3(t->sweep_blocks, 1, t->B), dim3(kScanThreads), 0, s, a);
+            return TSP_OK;
+        }
+    }
     if (mode == TSP_2OPT_BEST) {
         const dim3 g = scan_grid<TSP_2OPT_BEST>(t);
         if (a.recs)
@@ -784,6 +1192,11 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         if (done) { if (all_done) *all_done = 1; break; }
         if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
     }
+    if (mode == TSP_2OPT_BEST && !tabu && sorted_sweep(t)) {
+        launch_flush(t);
+        TSP_HIP_TRY(hipGetLastError());
+        if (sync) TSP_HIP_TRY(hipStreamSynchronize(s));
+    }
     if (status == TSP_TIME_LIMIT_EXCEEDED && mode == TSP_2OPT_BEST) {
         // the reference recomputes the cost on every exit path (tabusearch.c:168-172)
         launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
@@ -837,6 +1250,19 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     const size_t bn = (size_t)B * inst->n;
     const dim3 gb = scan_grid<TSP_2OPT_BEST>(t), gf = scan_grid<TSP_2OPT_FIRST>(t);
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
+    t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 4096);
+    size_t rec_per_tour = (size_t)inst->n;
+    if (inst->d_sperm) {
+        // k_sweep blocks per tour: whole clusters, about two waves per SIMD on the chip for one tour
+        const int want = env_int("TSP_SWEEP_BLOCKS", std::min(512, std::max(16, 512 / B)));
+        t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
+        rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
+        t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
+        TSP_HIP_TRY(hipMalloc(&t->d_gmax, (size_t)B * (inst->ng + 1) * sizeof(double)));
+        TSP_HIP_TRY(hipMalloc(&t->d_gbest, (size_t)B * sizeof(unsigned long long)));
+        TSP_HIP_TRY(hipMalloc(&t->d_order2, (size_t)B * inst->n * sizeof(int)));
+        TSP_HIP_TRY(hipMalloc(&t->d_pos2, (size_t)B * inst->n * sizeof(int)));
+    }
     TSP_HIP_TRY(hipMalloc(&t->d_order, bn * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_order0, bn * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_pos, bn * sizeof(int)));
@@ -845,7 +1271,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipMalloc(&t->d_slot_evals, (size_t)B * t->partial_per_tour * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_ticket, (size_t)B * sizeof(int)));
     t->use_recs = env_int("TSP_BEST_RECS", 1);
-    TSP_HIP_TRY(hipMalloc(&t->d_rec, bn * sizeof(NodeRec)));
+    TSP_HIP_TRY(hipMalloc(&t->d_rec, (size_t)B * rec_per_tour * sizeof(NodeRec)));
     t->max_tile_rows = std::max((int)gb.y, (int)gf.y);
     TSP_HIP_TRY(hipMalloc(&t->d_row_ticket, (size_t)B * t->max_tile_rows * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_row_evals, (size_t)B * t->max_tile_rows * sizeof(int)));
@@ -861,6 +1287,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipStreamSynchronize(t->inst->ctx->stream);
     (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
     (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
+    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
@@ -963,6 +1390,7 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     for (int r = 0; r < reps; ++r) launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);   // back to back on the engine's stream
     TSP_HIP_TRY(hipEventRecord(e1, s));
     TSP_HIP_TRY(hipEventSynchronize(e1));
+    if (sorted_sweep(t)) { launch_flush(t); TSP_HIP_TRY(hipStreamSynchronize(s)); }
     {
         float ms = 0.f;
         TSP_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -1094,6 +1522,12 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
 }
 
 #ifdef TSP_STAMPS
+int tsp_dev_debug_sweep(unsigned long long *out8192) {
+    if (hipMemcpyFromSymbol(out8192, HIP_SYMBOL(tsp::g_blk), 8192 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    static unsigned long long z[8192];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_blk), z, sizeof z);
+    return 0;
+}
 // diagnostic: mean 100 MHz ticks per segment of the last block of a step; resets the sums
 int tsp_dev_debug_stamps(double *out16) {
     unsigned long long h[16], nn = 0;
