@@ -34,7 +34,8 @@ constexpr int kMaxRowsPerBlock = 256;
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_stamp_sum[16];
 __device__ unsigned long long g_stamp_n;
-__device__ unsigned long long g_blk[1024][8];   // per k_sweep block (plain accumulation): launches, kept, ticks tests->staged, ticks tests->loop end
+__device__ unsigned long long g_blk[1024][8];
+__device__ unsigned long long g_blk2[1024][4];   // wave 0 of each block: row quads, quads entering tier 1, tier 2, diagonal half-units   // per k_sweep block (plain accumulation): launches, kept, ticks tests->staged, ticks tests->loop end
 __device__ unsigned long long g_sw_cnt[8];   // k_sweep: survivors kept, max kept, row quads, with tier 1, with exact, blocks, loop ticks, max loop ticks
 __device__ unsigned long long g_clk_core, g_clk_real;   // row-loop time of every block: shader cycles vs 100 MHz ticks
 #define TSP_STAMP(k) do { if (threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
@@ -745,6 +746,12 @@ __device__ __forceinline__ double gbest_load(unsigned long long *g) {
     return __longlong_as_double((long long)__hip_atomic_load((gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// v of lane l (l wave-uniform) in every lane, through two v_readlane_b32
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 // Group pair number t (0 <= t < ng (ng + 1) / 2, rows first) -> (row group r, column group c >= r).
 __device__ __forceinline__ void group_pair(int t, int ng, int &r, int &c) {
     const double b = 2.0 * ng + 1.0;
@@ -758,7 +765,7 @@ __device__ __forceinline__ void group_pair(int t, int ng, int &r, int &c) {
 }
 
 constexpr int kSweepCluster = 8;      // blocks that test the same group pairs and deal the survivors among themselves
-constexpr int kSweepRows = 32;        // rows of one unit of wave work
+constexpr int kSweepRows = 16;        // rows of one unit of wave work (64 / kSweepRows units per group pair)
 constexpr int kSweepStage = 8;        // group pairs whose records a block holds in LDS at a time (6 KB each)
 constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are processed in further passes)
 
@@ -783,6 +790,7 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
 #ifdef TSP_STAMPS
     const unsigned long long bt0 = wall_clock64();
     unsigned long long bt3 = 0;
+    unsigned long long dq = 0, dq1 = 0, dq2 = 0, ddiag = 0;
 #endif
     const int tour = blockIdx.z;
     const TourState *st = a.states + tour;
@@ -881,22 +889,26 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
 #ifdef TSP_STAMPS
             if (tid == 0 && blockIdx.x < 1024 && e0 == 0) { bt3 = wall_clock64(); g_blk[blockIdx.x][3] += bt3 - lt0; }
 #endif
-        for (int ht = wave; ht < 2 * ne; ht += NW) {
-            const int e = s_list[e0 + (ht >> 1)];
-            const int r = e >> 16, cgp = e & 0xffff, row0 = (ht & 1) * kSweepRows;
-            const NodeRec *rows = &s_stage[ht >> 1][row0];
-            const NodeRec rj = s_stage[ht >> 1][64 + lane];
+        constexpr int UPP = 64 / kSweepRows;   // units per group pair
+        for (int ht = wave; ht < UPP * ne; ht += NW) {
+            const int pe = ht / UPP;             // staged pair
+            const int e = s_list[e0 + pe];
+            const int r = e >> 16, cgp = e & 0xffff, row0 = (ht % UPP) * kSweepRows;
+            const NodeRec *rows = &s_stage[pe][row0];
+            const NodeRec rj = s_stage[pe][64 + lane];
             const double cds = rj.ds + prune2, cds2 = rj.ds + a.sum_margin;
             double bound = bd;   // the lane's own best so far
             // Rows that cannot reach the column group's box at all are dropped for the whole wave (one row per
             // lane, one ballot): about 60 % of the rows of a surviving group pair.  bound = 0 here: the test must
             // hold for every lane, and a lane that has found nothing yet has no better bound.
             unsigned alive;
+            double hx, hy, hd;   // lane l holds row l & 31: x, y, length of its tour edge
             {
-                const double4 cb = s_cbox[ht >> 1];
+                const double4 cb = s_cbox[pe];
                 const NodeRec &rr = rows[lane & (kSweepRows - 1)];
+                hx = rr.x; hy = rr.y; hd = rr.ds;
                 const double gx = fmax(0.0, fmax(cb.x - rr.x, rr.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rr.y, rr.y - cb.w));
-                const double T = rr.ds + s_cgmax[ht >> 1] + prune2;
+                const double T = rr.ds + s_cgmax[pe] + prune2;
                 const bool reach = lane < kSweepRows && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
                 alive = __builtin_amdgcn_readfirstlane((unsigned)__ballot(reach));
             }
@@ -906,34 +918,43 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
                 // margin  <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2.  All four rows in straight-line code.
                 bool ok[4];
                 bool any2 = false;
+                NodeRec ri[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ri[u] = rows[idx[u]];   // all LDS reads in flight before the first use
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const NodeRec &ri = rows[idx[u]];
-                    const double dx1 = ri.x - rj.x, dy1 = ri.y - rj.y;
-                    const double dx = ri.xs - rj.xs, dy = ri.ys - rj.ys, T2 = ri.ds + bound + cds2;
+                    const double dx1 = ri[u].x - rj.x, dy1 = ri[u].y - rj.y;
+                    const double dx = ri[u].xs - rj.xs, dy = ri[u].ys - rj.ys, T2 = ri[u].ds + bound + cds2;
                     const double sc = ATT10 ? 0.1 : 1.0;
                     const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
                     const double w = T2 * T2 - p1 - p2;
-                    // one slot pair once (inside a group: row slot below column slot), never adjacent nodes
-                    ok[u] = need[u] && T2 > 0.0 && w > 0.0 && 4.0 * p1 * p2 < w * w &&
-                            (cgp > r || row0 + idx[u] < lane) && ri.id >= 0 && rj.id >= 0 &&
-                            rj.id != ri.succ && rj.succ != ri.id;
-                    any2 = any2 || ok[u];
+                    // one slot pair once (inside a group: row slot below column slot), never adjacent nodes;
+                    // '&' on purpose: straight-line code, no branch per condition
+                    ok[u] = need[u] & (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
+                            ((cgp > r) | (row0 + idx[u] < lane)) & (ri[u].id >= 0) & (rj.id >= 0) &
+                            (rj.id != ri[u].succ) & (rj.succ != ri[u].id);
+                    any2 = any2 | ok[u];
                 }
                 if (any2) {   // tier 2: the exact delta
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (ok[u]) {
-                            const NodeRec ri = rows[idx[u]];
-                            const double delta = pair_delta<WT, INT>(ri, rj);
-                            const u64 kk = make_key(min(ri.id, rj.id), max(ri.id, rj.id));
+                            const double delta = pair_delta<WT, INT>(ri[u], rj);
+                            const u64 kk = make_key(min(ri[u].id, rj.id), max(ri[u].id, rj.id));
                             if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) { bd = delta; key = kk; bound = bd; }
                         }
                     }
                 }
             };
             // four live rows at a time (a short last group repeats its last row: the same pair twice changes nothing)
+#ifdef TSP_STAMPS
+            ddiag += (cgp == r) ? 1 : 0;
+#endif
             while (alive) {
+#ifdef TSP_STAMPS
+                dq += 1;
+                const unsigned long long ch0 = clock64();
+#endif
                 int idx[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -944,13 +965,20 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
                 bool any = false;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin
-                    const NodeRec &ri = rows[idx[u]];
-                    const double dx = ri.x - rj.x, dy = ri.y - rj.y, T = ri.ds + bound + cds;
+                    // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin.  The row's x, y and
+                    // edge length come out of lane idx[u]'s registers (v_readlane): no LDS round trip in the hot path.
+                    const double rx = lane_bcast(hx, idx[u]), ry = lane_bcast(hy, idx[u]), rd = lane_bcast(hd, idx[u]);
+                    const double dx = rx - rj.x, dy = ry - rj.y, T = rd + bound + cds;
                     need[u] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);   // T <= 0: never
                     any = any || need[u];
                 }
+#ifdef TSP_STAMPS
+                const unsigned long long c2 = clock64();
+                dq1 += c2 - ch0;
+                if (any) { rare4(idx, need); dq2 += clock64() - c2; }
+#else
                 if (any) rare4(idx, need);
+#endif
             }
         }
 #ifdef TSP_STAMPS
@@ -966,6 +994,9 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
     __shared__ double s_d[NW];
     __shared__ u64 s_k[NW];
     __shared__ int s_last;
+#ifdef TSP_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) { g_blk2[blockIdx.x][0] += dq; g_blk2[blockIdx.x][1] += dq1; g_blk2[blockIdx.x][2] += dq2; g_blk2[blockIdx.x][3] += ddiag; }
+#endif
     TSP_STAMP(2);
     block_argmin<true>(bd, key, s_d, s_k);
     TSP_STAMP(3);
@@ -1254,7 +1285,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     size_t rec_per_tour = (size_t)inst->n;
     if (inst->d_sperm) {
         // k_sweep blocks per tour: whole clusters, about two waves per SIMD on the chip for one tour
-        const int want = env_int("TSP_SWEEP_BLOCKS", std::min(512, std::max(16, 512 / B)));
+        const int want = env_int("TSP_SWEEP_BLOCKS", std::min(768, std::max(16, 768 / B)));
         t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
         rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
@@ -1522,6 +1553,12 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
 }
 
 #ifdef TSP_STAMPS
+int tsp_dev_debug_sweep2(unsigned long long *out4096) {
+    if (hipMemcpyFromSymbol(out4096, HIP_SYMBOL(tsp::g_blk2), 4096 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    static unsigned long long z[4096];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_blk2), z, sizeof z);
+    return 0;
+}
 int tsp_dev_debug_sweep(unsigned long long *out8192) {
     if (hipMemcpyFromSymbol(out8192, HIP_SYMBOL(tsp::g_blk), 8192 * sizeof(unsigned long long)) != hipSuccess) return -1;
     static unsigned long long z[8192];
