@@ -238,7 +238,7 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
             b.x = std::min(b.x, xy[2 * v]); b.y = std::max(b.y, xy[2 * v]);
             b.z = std::min(b.z, xy[2 * v + 1]); b.w = std::max(b.w, xy[2 * v + 1]);
         }
-        inst->ng = ng; inst->n_slots = n_slots;
+        inst->ng = ng; inst->n_slots = n_slots; inst->h_gbox = gbox;
         TSP_HIP_TRY(hipMalloc(&inst->d_sperm, sizeof(int) * (size_t)n_slots));
         TSP_HIP_TRY(hipMalloc(&inst->d_gbox, sizeof(double4) * ((size_t)ng + 1)));
         TSP_HIP_TRY(hipMemcpyAsync(inst->d_sperm, sperm.data(), sizeof(int) * (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));

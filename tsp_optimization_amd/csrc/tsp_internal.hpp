@@ -70,6 +70,7 @@ struct tsp_dev_inst {
     // d_gbox[g] = {min x, max x, min y, max y} of group g's nodes (the padding group sits far away).
     int *d_sperm = nullptr;
     double4 *d_gbox = nullptr;
+    std::vector<double4> h_gbox;   // host copy (pair table of the sorted sweep)
     int ng = 0, n_slots = 0;
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
 };
@@ -96,6 +97,7 @@ struct tsp_dev_tours {
     unsigned long long *d_gbest = nullptr;  // B: best delta any block has found so far in the running sweep (bits)
     int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep
     int sweep_blocks = 512;          // k_sweep blocks per tour
+    int *d_pairtab = nullptr;        // group pairs per cluster of k_sweep blocks (host-built), or nullptr
     int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
     int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)
     tsp::Partial *d_row_slot = nullptr;

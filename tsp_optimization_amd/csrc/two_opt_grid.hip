@@ -199,6 +199,7 @@ struct StepArgs {
     double prune;      // new-edge bound margin (tsp_dist.hpp); 1e300 = never prune
     // sorted sweep (k_sweep): records in Hilbert-rank order, group boxes, per-group longest edge, shared bound
     double sum_margin; // k_sweep tier 1: rounding of the two new distances + fp slack (doubled: keeps ties)
+    const int *pairtab;    // k_sweep: group pairs (r << 16 | c, -1 = none) per cluster, or nullptr (computed)
     int *orders2, *poss2;  // k_sweep / k_move_recs: the second copy of order/pos (TourState::parity says which is current)
     const double4 *gbox;
     const double *gmax;
@@ -780,7 +781,7 @@ constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are 
 // waves of a block share nothing until the block's arg-min.  Rows go four at a time so that the LDS reads and the
 // fp64 chains of different rows overlap.
 template <int WT, bool INT>
-__global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
+__global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {   // 3 waves per SIMD: 768 blocks resident
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
     constexpr int NW = kScanThreads / 64;
 #ifdef TSP_STAMPS
@@ -819,17 +820,32 @@ __global__ __launch_bounds__(kScanThreads) void k_sweep(const StepArgs a) {
         // (the pass ends on a condition every block of the cluster evaluates alike, or their ranks would part)
         int kept = 0;      // entries in s_list (same value in every thread)
         const int seen0 = seen;
+        int e_first = -1;   // the first round's table entry is on its way while the control block is read
+        if (a.pairtab && m0 + tid < ntests) e_first = a.pairtab[(size_t)q * ntests + m0 + tid];
+        bool first_round = true;
         while (m0 < ntests && (seen - seen0) / kSweepCluster + kScanThreads / kSweepCluster + 2 <= kSweepListCap) {
             const int m = m0 + tid;
             bool surv = false;
             int r = 0, c = 0;
-            if (m < ntests && Q * m + (q + 29 * m) % Q < npairs) {
+            bool valid = false;
+            if (a.pairtab) {
+                // host-built table: the group pairs in order of box distance, dealt to the clusters in turn, so that
+                // every cluster (and, rank by rank, every block of it) gets its share of the near pairs, which
+                // always survive and cost the most
+                const int e = first_round ? e_first : (m < ntests ? a.pairtab[(size_t)q * ntests + m] : -1);
+                valid = e >= 0; r = e >> 16; c = e & 0xffff;
+            } else if (m < ntests && Q * m + (q + 29 * m) % Q < npairs) {
                 // pair number: stride Q with a rotation per stride block (a plain stride would hand a cluster a
                 // lattice in (r, c) that can sit on the diagonal, where every pair survives)
                 group_pair(Q * m + (q + 29 * m) % Q, ng, r, c);
+                valid = true;
+            }
+            first_round = false;
+            if (valid) {
                 const double4 rb = a.gbox[r], cb = a.gbox[c];
                 const double gx = fmax(0.0, fmax(rb.x - cb.y, cb.x - rb.y)), gy = fmax(0.0, fmax(rb.z - cb.w, cb.z - rb.w));
-                const double T = gmax[r] + gmax[c] + prune2;   // bound 0: nothing is known about this sweep yet
+                // bound 0: nothing is known about this sweep yet
+                const double T = gmax[r] + gmax[c] + prune2;
                 surv = gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
             }
             const unsigned long long bal = __ballot(surv);
@@ -1090,6 +1106,7 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.margin = t->inst->filter_margin;
     a.prune = t->inst->prune_margin;
     a.sum_margin = t->inst->sum_margin;
+    a.pairtab = t->d_pairtab;
     a.orders2 = t->d_order2; a.poss2 = t->d_pos2;
     a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax; a.gbest = t->d_gbest;
     a.ng = t->inst->ng; a.n_slots = t->inst->n_slots;
@@ -1289,6 +1306,25 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
         rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
+        const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
+        if (npairs <= (1ll << 24) && inst->ng < 65535 && env_int("TSP_SWEEP_TABLE", 1)) {
+            // group pairs by box distance, dealt to the clusters in turn (see k_sweep)
+            const int ng = inst->ng, Q = t->sweep_blocks / kSweepCluster;
+            const long long ntests = (npairs + Q - 1) / Q;
+            std::vector<std::pair<double, int>> pr((size_t)npairs);
+            size_t w = 0;
+            for (int r = 0; r < ng; ++r)
+                for (int c = r; c < ng; ++c) {
+                    const double4 &rb = inst->h_gbox[r], &cb = inst->h_gbox[c];
+                    const double gx = std::max(0.0, std::max(rb.x - cb.y, cb.x - rb.y)), gy = std::max(0.0, std::max(rb.z - cb.w, cb.z - rb.w));
+                    pr[w++] = {gx * gx + gy * gy, (r << 16) | c};
+                }
+            std::sort(pr.begin(), pr.end());
+            std::vector<int> tab((size_t)Q * ntests, -1);
+            for (long long k = 0; k < npairs; ++k) tab[(size_t)(k % Q) * ntests + (size_t)(k / Q)] = pr[(size_t)k].second;
+            TSP_HIP_TRY(hipMalloc(&t->d_pairtab, tab.size() * sizeof(int)));
+            TSP_HIP_TRY(hipMemcpy(t->d_pairtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         TSP_HIP_TRY(hipMalloc(&t->d_gmax, (size_t)B * (inst->ng + 1) * sizeof(double)));
         TSP_HIP_TRY(hipMalloc(&t->d_gbest, (size_t)B * sizeof(unsigned long long)));
         TSP_HIP_TRY(hipMalloc(&t->d_order2, (size_t)B * inst->n * sizeof(int)));
@@ -1318,7 +1354,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipStreamSynchronize(t->inst->ctx->stream);
     (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
     (void)hipFree(t->d_state); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
-    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2);
+    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
