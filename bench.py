@@ -200,50 +200,54 @@ def main():
     }
 
     if rank == 0:
-        # roofline of the dominant kernel (k_scan, best-improvement sweep), HIP events on its stream
+        # roofline of the dominant kernel (best-improvement sweep), HIP events on its stream
         ms, evals_per_launch = tours.time_scan(reps=50)
         achieved = evals_per_launch * ALGO_BYTES_PER_EVAL / (ms * 1e-3) / 1e9
         traffic = None
         tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tj):
             with open(tj) as f:
-                traffic = json.load(f).get("k_step_best_n10000_hbm_bytes_per_launch")
-        # transparency: the same sweep with the new-edge bound off (every pair gets both raw roots) and with
-        # both bounds off (every pair gets the exact delta), on a fresh copy of the same start tour
+                traffic = json.load(f).get("sweep_n10000_hbm_bytes_per_launch")
+        # transparency: the same sweep (a) through the tiled kernel that visits every pair with the per-pair bounds,
+        # (b) with the new-edge bound off (every pair gets both raw roots), (c) with both bounds off (every pair
+        # gets the exact delta), each on a fresh copy of the same start tour
         variants = {}
         for label, env in (() if (args.no_variants or args.no_extras) else
-                           (("no_new_edge_bound", {"TSP_NO_PRUNE": "1"}), ("every_pair_exact", {"TSP_NO_FILTER": "1"}))):
+                           (("tiled_every_pair_visited", {"TSP_SORTED_MIN_N": "1000000000"}),
+                            ("tiled_no_new_edge_bound", {"TSP_NO_PRUNE": "1"}),
+                            ("tiled_every_pair_exact", {"TSP_NO_FILTER": "1"}))):
             os.environ.update(env)
             inst_v = E.Instance(ctx, xy, wt, 1)
+            tours_v = E.Tours(inst_v, 1)
             for k in env:
                 del os.environ[k]
-            tours_v = E.Tours(inst_v, 1)
             tours_v.upload(succ0[0], obj0[0])
             ms_v, ev_v = tours_v.time_scan(reps=30)
             variants[label] = {"kernel_ms": ms_v, "evals_per_s": ev_v / (ms_v * 1e-3)}
             tours_v.close()
             inst_v.close()
         out["roofline"] = {
-            "kernel": "tsp::k_step<EUC_2D integer-coordinate variant, BEST, RJ=2> (one sweep + move, n=10000), "
-                      "preceded in every launch by tsp::k_recs (per-node records of the current tour); kernel_ms "
-                      "is the HIP-event time of the pair, back to back (rocprof, profiles/r01_kernel_stats.csv: "
-                      "k_step 37.4 us + k_recs 4.9 us)",
+            "kernel": "tsp::k_sweep<EUC_2D integer-coordinate variant> (one best-improvement sweep of n=10000 + "
+                      "choice of the move), preceded in every launch by tsp::k_move_recs (carries out the previous "
+                      "move, rebuilds the per-node records); kernel_ms is the HIP-event time of the pair, back to "
+                      "back, at the start tour (rocprof means: profiles/r01_kernel_stats.csv)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": ms, "evals_per_launch": evals_per_launch,
             "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
             "note": "achieved = evals/launch x 72 B (operands the reference touches per delta evaluation) / "
-                    "kernel time; the tiled sweep re-uses operands on chip, so real HBM traffic (traffic) is "
-                    "far below it and frac can exceed 1: the kernel is fp64-VALU bound, see DESIGN.md.  An "
-                    "evaluation = one pair decided exactly as the reference decides it; two rigorous lower bounds "
-                    "(new-edge bound, raw-root bound) let most pairs be decided without the exact roots -- "
-                    "`variants` gives the same sweep with them switched off",
+                    "kernel time, as the measurement contract defines it.  The sweep keeps its operands on chip and "
+                    "decides most pairs by rigorous bounds (an evaluation = one pair decided exactly as the "
+                    "reference decides it: whole 64 x 64 blocks of pairs by the box form of the new-edge bound, "
+                    "single pairs by the new-edge bound, by both new edges without a root, the rest by the exact "
+                    "delta), so real HBM traffic (traffic) is far below the algorithmic bytes and frac exceeds 1: "
+                    "the step is bound by launch and memory latencies, not by HBM or VALU throughput, see "
+                    "DESIGN.md.  `variants` gives the same sweep with the bounds switched off one by one",
             "variants": variants,
-            "valu": {"measured": "profiles/r01_pmc_sq_wave_counters.json",
-                     "note": "rocprofv3 SQ counters of this kernel: ~15 VALU wave-instructions per wave of 64 "
-                             "evaluations (common path: 2 sub, mul, fma, add, mul, 2 compares), SQ_ACTIVE_INST_VALU "
-                             "~ 50-65 % of the launch's SIMD-cycles; the rest of a wave's life is the synchronised "
-                             "tile prologue / epilogue phases"},
+            "counters": {"measured": "profiles/r01_pmc_sq_wave_counters.json",
+                         "note": "rocprofv3 SQ counters of k_sweep: the average wave lives ~3 us of the ~16 us "
+                                 "launch; the launch is the critical path tests -> records into LDS -> pair loop "
+                                 "of the busiest block -> hand-off -> arg-min over the blocks"},
         }
 
     if rank == 0 and world == 1 and not args.no_extras:
