@@ -125,3 +125,48 @@ def test_sorted_and_tiled_sweeps_agree_move_for_move(eng, ctx, monkeypatch, name
     keys = ("sweeps", "evals", "moves", "reversed", "pairs_scanned", "steps")
     assert [out[0][1][k] for k in keys] == [out[1][1][k] for k in keys]
     assert out[0][1]["moves"] >= min(steps, 90)
+
+
+@pytest.mark.parametrize("name", ["att532", "rand2000", "d493"])
+def test_first_improvement_both_kernel_forms_agree(eng, ctx, monkeypatch, name):
+    """k_first (fixed grid, out-of-place moves, two control-block slots) against k_step<FIRST> (the first form),
+    and both against the oracle's alg_2opt counters."""
+    xy, wt = load_instance(name)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    _, es, eo, est, _ = O.two_opt_first(xy, wt, succ0, obj0)
+    for v1 in ("0", "1"):
+        for gy, rj in (("8", "2"), ("3", "1"), ("64", "2")):
+            monkeypatch.setenv("TSP_FIRST_V1", v1)
+            monkeypatch.setenv("TSP_FIRST_GRID_ROWS", gy)
+            monkeypatch.setenv("TSP_FIRST_RJ", rj)
+            inst = eng.Instance(ctx, xy, wt, 1)
+            rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.FIRST, engine=1)
+            inst.close()
+            assert (s == es).all() and o == eo, (v1, gy, rj)
+            assert (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == \
+                (est["sweeps"], est["evals"], est["moves"], est["reversed"]), (v1, gy, rj)
+
+
+def test_first_then_best_then_first_on_one_handle(eng, ctx):
+    """Runs of both rules on the same resident tours: every run leaves the tour in the first copy of order/pos
+    and the control block in a slot the next run finds."""
+    xy, wt = load_instance("pr1002")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ0, obj0)
+    tours.run(eng.FIRST, max_steps=37)
+    tours.run(eng.BEST, max_steps=5)
+    tours.run(eng.FIRST, max_steps=11)
+    s, o, st = tours.download()
+    assert O.is_tour(s[0])
+    # replay on the CPU: 37 first-improvement steps cannot be cut out of the oracle's loop, so check invariants:
+    # the running cost of a first-improvement run started from the true cost stays the true cost
+    tours2 = eng.Tours(inst, 1)
+    tours2.upload(s[0], O.succ_cost(xy, wt, s[0]))
+    rc, done = tours2.run(eng.FIRST)
+    s2, o2, _ = tours2.download()
+    assert done and O.is_tour(s2[0]) and o2[0] == O.succ_cost(xy, wt, s2[0])
+    _, es, eo, _, _ = O.two_opt_first(xy, wt, s[0], O.succ_cost(xy, wt, s[0]))
+    assert (s2[0] == es).all() and o2[0] == eo
+    tours.close(); tours2.close(); inst.close()

@@ -89,7 +89,9 @@ struct tsp_dev_tours {
     int *d_order = nullptr;          // B x n : node at tour position p
     int *d_pos = nullptr;            // B x n : position of node v
     int *d_order2 = nullptr, *d_pos2 = nullptr;   // second copies (sorted sweep: moves are applied out of place)
-    tsp::TourState *d_state = nullptr;
+    tsp::TourState *d_state = nullptr;       // the current control blocks: d_state_base + slot * B
+    tsp::TourState *d_state_base = nullptr;  // 2 x B: k_first reads one slot and writes the other
+    int slot = 0;
     tsp::Partial *d_partial = nullptr;
     size_t partial_per_tour = 0;
     tsp::NodeRec *d_rec = nullptr;   // B x max(n, n_slots) node records, rebuilt before every BEST step (k_recs*)
@@ -111,6 +113,10 @@ struct tsp_dev_tours {
     tsp::TourState *h_state = nullptr;
     // scan geometry
     int first_rows_per_block = 8;
+    int first_grid_rows = 32;        // k_first: tile rows of its fixed grid
+    int first_rj = 1;                // k_first: columns per lane
+    int first_max_rows2 = 2048;      // k_first: largest chunk
+    int first_v1 = 0;                // use k_step<FIRST> (the first form) instead of k_first
     int first_min_rows = 8;
     int first_max_rows = 2048;
     int best_rows_per_block = 32;
