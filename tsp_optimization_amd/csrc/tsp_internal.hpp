@@ -99,6 +99,7 @@ struct tsp_dev_tours {
     unsigned long long *d_gbest = nullptr;  // B: best delta any block has found so far in the running sweep (bits)
     int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep
     int sweep_blocks = 512;          // k_sweep blocks per tour
+    int *d_cl_ticket = nullptr;      // k_sweep: arrival counters per tour x cluster
     int *d_pairtab = nullptr;        // group pairs per cluster of k_sweep blocks (host-built), or nullptr
     int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
     int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)

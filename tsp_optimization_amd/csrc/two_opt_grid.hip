@@ -201,6 +201,7 @@ struct StepArgs {
     // sorted sweep (k_sweep): records in Hilbert-rank order, group boxes, per-group longest edge, shared bound
     double sum_margin; // k_sweep tier 1: rounding of the two new distances + fp slack (doubled: keeps ties)
     const int *pairtab;    // k_sweep: group pairs (r << 16 | c, -1 = none) per cluster, or nullptr (computed)
+    int *cl_tickets;       // k_sweep: per tour x cluster arrival counters, 64 ints apart
     int *orders2, *poss2;  // k_sweep / k_move_recs: the second copy of order/pos (TourState::parity says which is current)
     const double4 *gbox;
     const double *gmax;
@@ -1022,9 +1023,16 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
         publish_partial(a.partials + slot_idx, bd, key_i(key), key_j(key));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
         TSP_STAMP(4);
-        const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old + 1 == (int)gridDim.x);
-        if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrivals on one word are served one after the other (~12 ns each): count per cluster first (one word per
+        // cluster, 256 B apart), then the clusters on the tour's word
+        gi32 *ct = (gi32 *)(a.cl_tickets + ((size_t)tour * Q + q) * 64);
+        s_last = 0;
+        if (__hip_atomic_fetch_add(ct, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == kSweepCluster) {
+            __hip_atomic_store(ct, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old + 1 == Q);
+            if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     if (!s_last) return;
@@ -1083,13 +1091,13 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     // `active` of them take a ticket, and block `widx` carries out slices widx, widx + active, ... of the pending
     // move -- only ticket holders touch the other copy, so all of it is written before the last block moves on.
     const int tile_rows = (row_hi - row_lo + rpb - 1) / rpb;
-    __shared__ int s_active, s_widx;
+    __shared__ int s_active, s_widx, s_rowblocks;
     if (tid < 64) {
         const int mine = tid < tile_rows ? gx - skipped_in_tile_row(row_lo + tid * rpb, gx, TJ) : 0;
         int incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const int t2 = __shfl_up(incl, off); if (tid >= off) incl += t2; }
-        if (tid == (int)blockIdx.y) s_widx = incl - mine + ((int)blockIdx.x - skipped_in_tile_row(r0, gx, TJ));
+        if (tid == (int)blockIdx.y) { s_widx = incl - mine + ((int)blockIdx.x - skipped_in_tile_row(r0, gx, TJ)); s_rowblocks = mine; }
         if (tid == 63) s_active = incl;
     }
     __syncthreads();
@@ -1149,9 +1157,16 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     if (tid == 0) {
         publish_partial(a.partials + (size_t)tour * a.partial_per_tour + (size_t)blockIdx.y * gx + blockIdx.x, bd, key_i(key), key_j(key));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
-        const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old + 1 == active);
-        if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrivals per tile row first (one word per row, 256 B apart), then the rows on the tour's word: arrivals on
+        // one word are served one after the other
+        gi32 *rt = (gi32 *)(a.cl_tickets + ((size_t)tour * 64 + blockIdx.y) * 64);
+        s_last = 0;
+        if (__hip_atomic_fetch_add(rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == s_rowblocks) {
+            __hip_atomic_store(rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (old + 1 == tile_rows);
+            if (s_last) __hip_atomic_store((gi32 *)(a.tickets + tour), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     if (!s_last) return;
@@ -1304,6 +1319,7 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.prune = t->inst->prune_margin;
     a.sum_margin = t->inst->sum_margin;
     a.pairtab = t->d_pairtab;
+    a.cl_tickets = t->d_cl_ticket;
     a.orders2 = t->d_order2; a.poss2 = t->d_pos2;
     a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax; a.gbest = t->d_gbest;
     a.ng = t->inst->ng; a.n_slots = t->inst->n_slots;
@@ -1522,12 +1538,14 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     t->partial_per_tour = std::max(t->partial_per_tour, (size_t)((inst->n + kScanThreads - 1) / kScanThreads) * t->first_grid_rows);
     t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 4096);
     size_t rec_per_tour = (size_t)inst->n;
+    size_t cl_words = (size_t)B * 64 * 64;   // k_first: one arrival counter per tour x tile row, 64 ints apart
     if (inst->d_sperm) {
         // k_sweep blocks per tour: whole clusters, about two waves per SIMD on the chip for one tour
         const int want = env_int("TSP_SWEEP_BLOCKS", std::min(768, std::max(16, 768 / B)));
         t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
         rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
+        cl_words = std::max(cl_words, (size_t)B * (t->sweep_blocks / kSweepCluster) * 64);
         const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
         if (npairs <= (1ll << 24) && inst->ng < 65535 && env_int("TSP_SWEEP_TABLE", 1)) {
             // group pairs by box distance, dealt to the clusters in turn (see k_sweep)
@@ -1551,6 +1569,8 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         TSP_HIP_TRY(hipMalloc(&t->d_gbest, (size_t)B * sizeof(unsigned long long)));
 
     }
+    TSP_HIP_TRY(hipMalloc(&t->d_cl_ticket, cl_words * sizeof(int)));
+    TSP_HIP_TRY(hipMemset(t->d_cl_ticket, 0, cl_words * sizeof(int)));   // every launch leaves them at zero
     TSP_HIP_TRY(hipMalloc(&t->d_order, bn * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_order2, bn * sizeof(int)));   // second copies: moves are carried out of place
     TSP_HIP_TRY(hipMalloc(&t->d_pos2, bn * sizeof(int)));
@@ -1578,7 +1598,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipStreamSynchronize(t->inst->ctx->stream);
     (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
     (void)hipFree(t->d_state_base); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
-    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab);
+    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
