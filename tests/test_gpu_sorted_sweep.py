@@ -170,3 +170,37 @@ def test_first_then_best_then_first_on_one_handle(eng, ctx):
     _, es, eo, _, _ = O.two_opt_first(xy, wt, s[0], O.succ_cost(xy, wt, s[0]))
     assert (s2[0] == es).all() and o2[0] == eo
     tours.close(); tours2.close(); inst.close()
+
+
+def test_sorted_sweep_several_tours_at_full_size(eng, ctx, monkeypatch):
+    """B = 3 random tours of a 4500-node instance: sorted and tiled sweeps agree move for move on every tour."""
+    xy = rand_instance(4500)
+    rng = np.random.default_rng(8)
+    succ0 = np.stack([random_tour(4500, rng) for _ in range(3)])
+    obj0 = np.zeros(3)
+    out = []
+    for min_n in ("0", "1000000000"):
+        monkeypatch.setenv("TSP_SORTED_MIN_N", min_n)
+        inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+        tours = eng.Tours(inst, 3)
+        tours.upload(succ0, obj0)
+        tours.run(eng.BEST, max_steps=60)
+        s, o, st = tours.download()
+        out.append((s.copy(), [(x["moves"], x["reversed"], x["evals"]) for x in st]))
+        tours.close(); inst.close()
+    assert (out[0][0] == out[1][0]).all() and out[0][1] == out[1][1]
+    assert all(m[0] == 60 for m in out[0][1])
+
+
+def test_sorted_sweep_time_limit_leaves_a_consistent_tour(eng, ctx):
+    """A run cut short by the time limit (tabusearch.c:131 checks it per sweep): status 2, a valid tour in the
+    first copy of order/pos, and the recomputed cost the reference reports on every exit path (:168-172)."""
+    xy, wt = load_instance("rand10000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=eng.BEST, time_limit=0.004)
+    assert rc == eng.TIME_LIMIT_EXCEEDED and 0 < st["sweeps"] < 1428
+    assert O.is_tour(s) and o == O.succ_cost(xy, wt, s)
+    rc2, s2, o2, st2 = inst.two_opt(s, o, mode=eng.BEST)          # and the descent can be resumed from it
+    assert rc2 == 0 and o2 == 75471617.0 and st["sweeps"] + st2["sweeps"] == 1428 + 0
+    inst.close()
