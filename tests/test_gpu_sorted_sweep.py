@@ -1,4 +1,4 @@
-"""GPU parity of the sorted best-improvement sweep (k_recs_sorted + k_sweep, two_opt_grid.hip).
+"""GPU parity of the sorted best-improvement sweep (k_move_recs + k_sweep, two_opt_sweep.hpp).
 
 By default the engine uses it for n >= 4096, where the CPU oracle needs minutes per descent; these tests set
 TSP_SORTED_MIN_N=0 so that the same kernels run on the small instances the oracle finishes in seconds, and check
