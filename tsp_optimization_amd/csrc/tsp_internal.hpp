@@ -96,7 +96,6 @@ struct tsp_dev_tours {
     size_t partial_per_tour = 0;
     tsp::NodeRec *d_rec = nullptr;   // B x max(n, n_slots) node records, rebuilt before every BEST step (k_recs*)
     double *d_gmax = nullptr;        // B x (ng + 1): longest tour edge leaving a node of the group (sorted sweep)
-    unsigned long long *d_gbest = nullptr;  // B: best delta any block has found so far in the running sweep (bits)
     int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep
     int sweep_blocks = 512;          // k_sweep blocks per tour
     int *d_cl_ticket = nullptr;      // k_sweep: arrival counters per tour x cluster

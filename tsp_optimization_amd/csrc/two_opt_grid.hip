@@ -65,7 +65,7 @@ dim3 scan_grid(const tsp_dev_tours *t) {
 
 int env_int(const char *name, int dflt);
 
-// BEST sweeps of this handle go through k_recs_sorted + k_sweep (no tabu list, metric with the new-edge bound)
+// BEST sweeps of this handle go through k_move_recs + k_sweep (no tabu list, metric with the new-edge bound)
 bool sorted_sweep(const tsp_dev_tours *t) {
     return t->inst->d_sperm && t->d_gmax && t->d_order2 && t->n >= t->sorted_min_n && t->inst->prune_margin < 1e299 &&
            t->inst->ng < 65535;   // k_sweep packs (r, c) into one int and counts group pairs in 31 bits
@@ -103,7 +103,7 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.pairtab = t->d_pairtab;
     a.cl_tickets = t->d_cl_ticket;
     a.orders2 = t->d_order2; a.poss2 = t->d_pos2;
-    a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax; a.gbest = t->d_gbest;
+    a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax;
     a.ng = t->inst->ng; a.n_slots = t->inst->n_slots;
     a.flat_slots = t->sweep_blocks;
     return a;
@@ -348,7 +348,6 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
             TSP_HIP_TRY(hipMemcpy(t->d_pairtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         TSP_HIP_TRY(hipMalloc(&t->d_gmax, (size_t)B * (inst->ng + 1) * sizeof(double)));
-        TSP_HIP_TRY(hipMalloc(&t->d_gbest, (size_t)B * sizeof(unsigned long long)));
 
     }
     TSP_HIP_TRY(hipMalloc(&t->d_cl_ticket, cl_words * sizeof(int)));
@@ -380,7 +379,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipStreamSynchronize(t->inst->ctx->stream);
     (void)hipFree(t->d_order); (void)hipFree(t->d_order0); (void)hipFree(t->d_pos);
     (void)hipFree(t->d_state_base); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
-    (void)hipFree(t->d_gmax); (void)hipFree(t->d_gbest); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
+    (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);

@@ -178,7 +178,6 @@ struct StepArgs {
     int *orders2, *poss2;  // k_sweep / k_move_recs: the second copy of order/pos (TourState::parity says which is current)
     const double4 *gbox;
     const double *gmax;
-    unsigned long long *gbest;
     int ng, n_slots, flat_slots;
 };
 

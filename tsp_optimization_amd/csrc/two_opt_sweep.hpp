@@ -86,11 +86,6 @@ __global__ void k_flush_state(TourState *states, int B) {
     if (b < B) { states[b].parity = 0; states[b].pending = 0; }
 }
 
-// Non-positive deltas order like their bit patterns read as unsigned (more negative = larger).
-__device__ __forceinline__ double gbest_load(unsigned long long *g) {
-    return __longlong_as_double((long long)__hip_atomic_load((gu64 *)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
 // v of lane l (l wave-uniform) in every lane, through two v_readlane_b32
 __device__ __forceinline__ double lane_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
