@@ -20,16 +20,43 @@
 
 namespace tsp {
 
+#ifdef TSP_STAMPS
+__device__ unsigned long long g_lds_prof[8];   // tour 0, thread 0: cycles in scan / arg-min / counters / move / control, steps
+#define LDS_T(k) do { const unsigned long long t_ = clock64(); prof[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define LDS_T(k) do { } while (0)
+#endif
+
 constexpr int kLdsThreads = 512;
 constexpr int kLdsRows = 32;
 using idx_t = unsigned short;
 
-__host__ __device__ inline size_t lds_bytes_needed(int n) {
-    // rows | coord | order | pos | reduction scratch
-    return sizeof(NodeRec) * kLdsRows + sizeof(double2) * (size_t)n + 2 * sizeof(idx_t) * (size_t)n + 1024;
+__host__ __device__ inline size_t lds_bytes_needed(int n, bool edge_cache = false) {
+    // rows | coord | order | pos | (edge lengths by position) | reduction scratch
+    return sizeof(NodeRec) * kLdsRows + sizeof(double2) * (size_t)n + 2 * sizeof(idx_t) * (size_t)n +
+           (edge_cache ? sizeof(float) * (size_t)n + 16 : 0) + 1024;
 }
 
-template <int WT, bool INT, int MODE>
+// Node record from the LDS arrays.  CACHE: d(v, succ v) is dsp[pos v] -- the tour's edge lengths by position, kept
+// as floats (integer costs < 2^24 on the integer-coordinate variants, exact), so that a step derives thousands of
+// column records without a single root; a move reverses the same sub-array of dsp and recomputes its two new edges.
+template <int WT, bool INT, bool CACHE>
+__device__ __forceinline__ NodeRec lds_node(const double2 *coord, const idx_t *order, const idx_t *pos, const float *dsp,
+                                            int n, int v) {
+    const int p = (int)pos[v];
+    int q = p + 1;
+    if (q == n) q = 0;
+    const int s = (int)order[q];
+    const double2 c = coord[v], cs = coord[s];
+    NodeRec r;
+    r.x = c.x; r.y = c.y; r.xs = cs.x; r.ys = cs.y;
+    if constexpr (CACHE) r.ds = (double)dsp[p];
+    else r.ds = dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
+    r.succ = s; r.id = v;
+    return r;
+}
+
+template <int WT, bool INT, int MODE, bool CACHE>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
@@ -41,6 +68,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     idx_t *pos = order + n;
     char *scratch = reinterpret_cast<char *>(pos + n);
     scratch += (16 - (reinterpret_cast<size_t>(scratch) & 15)) & 15;
+    float *dsp = reinterpret_cast<float *>(scratch);   // CACHE: edge length leaving tour position p
+    if constexpr (CACHE) {
+        scratch += sizeof(float) * (size_t)n;
+        scratch += (16 - (reinterpret_cast<size_t>(scratch) & 15)) & 15;
+    }
     double *s_d = reinterpret_cast<double *>(scratch);            // 16
     u64 *s_k = reinterpret_cast<u64 *>(scratch + 128);            // 16
     long long *s_ll = reinterpret_cast<long long *>(scratch + 256);  // 16
@@ -64,7 +96,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
               scanned = st->pairs_scanned, steps = st->steps;
     __syncthreads();
+    if constexpr (CACHE) {
+        for (int p = tid; p < n; p += kLdsThreads) {
+            const double2 c = coord[order[p]], cs = coord[order[p + 1 == n ? 0 : p + 1]];
+            dsp[p] = (float)dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
+        }
+        __syncthreads();
+    }
 
+#ifdef TSP_STAMPS
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     for (int iter = 0; iter < max_iters && !done; ++iter) {
         int row_lo = 0, row_hi = n - 1;
         if constexpr (MODE == TSP_2OPT_FIRST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
@@ -75,41 +117,84 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         for (int rb = row_lo; rb < row_hi; rb += kLdsRows) {
             const int nr = min(kLdsRows, row_hi - rb);
             __syncthreads();
-            if (tid < nr) s_rows[tid] = load_node<WT, INT>(coord, order, pos, n, rb + tid);
+            if (tid < nr) s_rows[tid] = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, rb + tid);
             __syncthreads();
-            for (int j = tid; j < n; j += kLdsThreads) {
-                if (j <= rb) continue;  // no row of this block is below column j
-                const NodeRec rj = load_node<WT, INT>(coord, order, pos, n, j);
-                for (int r = 0; r < nr; ++r) {
-                    const int i = rb + r;
-                    const NodeRec ri = s_rows[r];
-                    bool ok = j > i && j != ri.succ && rj.succ != i;  // heuristics.c:471 / tabusearch.c:134
-                    if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
-                    const u64 k = make_key(i, j);
-                    if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && k < key;
-                    if constexpr (has_root_filter<WT>()) {
-                        const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
-                        // a lane's keys are not visited in increasing order here, so BEST must keep ties
-                        // (an equal delta with a smaller key wins): skip only when provably greater
-                        // (the new-edge bound is written with its margin doubled so that "<" also keeps ties)
-                        ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + 2.0 * prune);
-                        if (ok) {
-                            const double lower = pair_delta_approx<WT>(ri, rj) - margin;
-                            ok = MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound;
+            // Columns four at a time: a column record is a chain of dependent LDS reads (pos -> order / edge length ->
+            // successor's coordinates); the four chains advance level by level, so a thread waits for LDS three
+            // times per four columns instead of three times per column (two waves per SIMD hide little).
+            // FIRST: the winner is the smallest key, and a hit in the block's first row ends the search: no later
+            // batch of columns can hold a smaller one (dense-improvement phases -- random individuals -- find it
+            // in the first batch after the cursor), so batches are 512 columns there and the block votes after each
+            // (512 then 2048 was measured: no better).
+            constexpr int U = MODE == TSP_2OPT_FIRST ? 1 : 4;
+            // batches that hold no column above the rows (or, for the cursor's row alone, above the cursor) are skipped
+            const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == ci) ? cj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
+            for (int j0 = jbase + tid; j0 - tid < n; j0 += U * kLdsThreads) {
+                int jj[U], pp[U], sc[U];
+                bool act[U];
+                double2 cxy[U], cs[U];
+                double dsv[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    jj[k] = j0 + k * kLdsThreads;
+                    act[k] = jj[k] < n && jj[k] > rb;   // no row of this block is below a column <= rb
+                    const int jc = act[k] ? jj[k] : 0;
+                    pp[k] = (int)pos[jc];
+                    cxy[k] = coord[jc];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int q = pp[k] + 1 == n ? 0 : pp[k] + 1;
+                    sc[k] = (int)order[q];
+                    if constexpr (CACHE) dsv[k] = (double)dsp[pp[k]];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) cs[k] = coord[sc[k]];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (!act[k]) continue;
+                    const int j = jj[k];
+                    NodeRec rj;
+                    rj.x = cxy[k].x; rj.y = cxy[k].y; rj.xs = cs[k].x; rj.ys = cs[k].y;
+                    if constexpr (CACHE) rj.ds = dsv[k];
+                    else rj.ds = dist_xy<WT, INT>(cxy[k].x, cxy[k].y, cs[k].x, cs[k].y);
+                    rj.succ = sc[k]; rj.id = j;
+                    for (int r = 0; r < nr; ++r) {
+                        const int i = rb + r;
+                        const NodeRec ri = s_rows[r];
+                        bool ok = j > i && j != ri.succ && rj.succ != i;  // heuristics.c:471 / tabusearch.c:134
+                        if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
+                        const u64 kq = make_key(i, j);
+                        if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && kq < key;
+                        if constexpr (has_root_filter<WT>()) {
+                            const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
+                            // a lane's keys are not visited in increasing order here, so BEST must keep ties
+                            // (an equal delta with a smaller key wins): skip only when provably greater
+                            // (the new-edge bound is written with its margin doubled so that "<" also keeps ties)
+                            ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + 2.0 * prune);
+                            if (ok) {
+                                const double lower = pair_delta_approx<WT>(ri, rj) - margin;
+                                ok = MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound;
+                            }
                         }
-                    }
-                    if (ok) {
-                        const double delta = pair_delta<WT, INT>(ri, rj);
-                        if constexpr (MODE == TSP_2OPT_FIRST) {
-                            if (delta < 0) { bd = delta; key = k; }
-                        } else {
-                            if (better(delta, k, bd, key)) { bd = delta; key = k; }
+                        if (ok) {
+                            const double delta = pair_delta<WT, INT>(ri, rj);
+                            if constexpr (MODE == TSP_2OPT_FIRST) {
+                                if (delta < 0) { bd = delta; key = kq; }
+                            } else {
+                                if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                            }
                         }
                     }
                 }
+                if constexpr (MODE == TSP_2OPT_FIRST) {
+                    if (__syncthreads_or(key != kNoKey && key_i(key) == rb)) break;
+                }
             }
         }
+        LDS_T(0);
         block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
+        LDS_T(1);
         const bool found = key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0);
         const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
 
@@ -132,6 +217,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             }
         }
 
+        LDS_T(2);
         // ---- move: reverse positions pa+1 .. pb (cyclic) --------------------------------------------
         int L = 0;
         if (found) {
@@ -146,9 +232,27 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 order[p] = w; order[q] = u;
                 pos[w] = (idx_t)p; pos[u] = (idx_t)q;
             }
+            if constexpr (CACHE) {
+                // the edges inside the reversed path keep their lengths and change places: positions
+                // pa+1 .. pb-1 of dsp are reversed; the two new edges leave positions pa and pb
+                const int inner = (L - 1) >> 1;
+                for (int t = tid; t < inner; t += kLdsThreads) {
+                    int p = pa + 1 + t; if (p >= n) p -= n;
+                    int q = pb - 1 - t; if (q < 0) q += n;
+                    const float u = dsp[p], w = dsp[q];
+                    dsp[p] = w; dsp[q] = u;
+                }
+                __syncthreads();   // order[] holds the new tour
+                if (tid < 2) {
+                    const int p = tid == 0 ? pa : pb;
+                    const double2 c = coord[order[p]], cs = coord[order[p + 1 == n ? 0 : p + 1]];
+                    dsp[p] = (float)dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
+                }
+            }
         }
         __syncthreads();
 
+        LDS_T(3);
         // ---- control block ----------------------------------------------------------------------------
         steps += 1;
         if constexpr (MODE == TSP_2OPT_BEST) {
@@ -161,13 +265,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 // recomputed cost, node order (tabusearch.c:168-172)
                 if constexpr (INT || WT == WT_CEIL_2D) {
                     double c = 0.0;
-                    for (int v = tid; v < n; v += kLdsThreads) c += load_node<WT, INT>(coord, order, pos, n, v).ds;
+                    for (int v = tid; v < n; v += kLdsThreads) c += lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, v).ds;
                     obj = block_sum<double>(c, s_d);
                 } else {
                     double acc = 0.0;
                     for (int base = 0; base < n; base += 64) {  // sequential order, 64 edges at a time
                         __syncthreads();
-                        if (tid < 64 && base + tid < n) s_chunk[tid] = load_node<WT, INT>(coord, order, pos, n, base + tid).ds;
+                        if (tid < 64 && base + tid < n) s_chunk[tid] = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, base + tid).ds;
                         __syncthreads();
                         const int m = min(64, n - base);
                         for (int t = 0; t < m; ++t) acc += s_chunk[t];  // every thread adds the same values in order
@@ -194,6 +298,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         }
     }
 
+#ifdef TSP_STAMPS
+    if (tour == 0 && tid == 0) { for (int k = 0; k < 4; ++k) g_lds_prof[k] += prof[k]; g_lds_prof[7] += steps - st->steps; }
+#endif
     // ---- write back ---------------------------------------------------------------------------------------
     __syncthreads();
     for (int v = tid; v < n; v += kLdsThreads) order_g[v] = (int)order[v];
@@ -219,30 +326,43 @@ int env_int(const char *name, int dflt) {
     return (v && *v) ? atoi(v) : dflt;
 }
 
+template <int WT, bool INT, int MODE, bool CACHE>
+hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
+    hipStream_t s = t->inst->ctx->stream;
+    const size_t bytes = lds_bytes_needed(t->n, CACHE);
+    auto k = k_lds_two_opt<WT, INT, MODE, CACHE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
+    return hipGetLastError();
+}
+
 template <int WT, bool INT>
 hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_iters) {
-    hipStream_t s = t->inst->ctx->stream;
-    const size_t bytes = lds_bytes_needed(t->n);
-    hipError_t e;
-    if (mode == TSP_2OPT_FIRST) {
-        auto k = k_lds_two_opt<WT, INT, TSP_2OPT_FIRST>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
-    } else {
-        auto k = k_lds_two_opt<WT, INT, TSP_2OPT_BEST>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                           rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
+    // integer-coordinate variants: integer edge lengths < 2^21, exact as floats
+    constexpr bool CAN_CACHE = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
+    if constexpr (CAN_CACHE) {
+        if (lds_bytes_needed(t->n, true) <= (size_t)160 * 1024 && env_int("TSP_LDS_EDGE_CACHE", 1))
+            return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, true>(t, rmin, rmax, max_iters)
+                                          : launch_lds_k<WT, INT, TSP_2OPT_BEST, true>(t, rmin, rmax, max_iters);
     }
-    return hipGetLastError();
+    return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, false>(t, rmin, rmax, max_iters)
+                                  : launch_lds_k<WT, INT, TSP_2OPT_BEST, false>(t, rmin, rmax, max_iters);
 }
 }  // namespace
 
 // implemented in two_opt_grid.hip
 int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+
+#ifdef TSP_STAMPS
+extern "C" int tsp_dev_debug_lds(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_lds_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_lds_prof), z, sizeof z);
+    return 0;
+}
+#endif
 
 bool tsp_lds_fits(const tsp_dev_inst *inst) {
     return inst && inst->n <= 65535 && lds_bytes_needed(inst->n) <= (size_t)160 * 1024;
