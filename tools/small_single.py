@@ -1,0 +1,38 @@
+"""single-tour descents on the reference's own instance sizes: GRID vs LDS engine, both rules (wall time of the call)."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+import numpy as np
+from tsp_optimization_amd import engine as E
+from helpers import load_instance
+ctx = E.Context(0)
+for name in ("berlin52", "pr299", "att532", "pr1002", "rand2000", "rand5000"):
+    xy, wt = load_instance(name)
+    inst = E.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(E.GREEDY, np.array([0], dtype=np.int32))
+    for mode, mn in ((E.FIRST, "FIRST"), (E.BEST, "BEST")):
+        row = []
+        for eng in (1, 2):
+            best = 1e9
+            for rep in range(4):
+                t0 = time.perf_counter()
+                rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=mode, engine=eng)
+                best = min(best, time.perf_counter() - t0)
+            row.append((best * 1e3, st["steps"]))
+        print("%-9s %-5s steps %5d: GRID %.3f ms  LDS %.3f ms" % (name, mn, row[0][1], row[0][0], row[1][0]))
+    inst.close()
+
+# fixed cost of a call: a descent that starts at a local optimum (one sweep, no move)
+for name in ("berlin52", "att532"):
+    xy, wt = load_instance(name)
+    inst = E.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(E.GREEDY, np.array([0], dtype=np.int32))
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=E.FIRST, engine=1)
+    for eng in (1, 2):
+        ts = []
+        for rep in range(20):
+            t0 = time.perf_counter()
+            rc, s2, o2, st2 = inst.two_opt(s, o, mode=E.FIRST, engine=eng)
+            ts.append(time.perf_counter() - t0)
+        print("%-9s at its local optimum, engine %d: %.3f ms per call (%d steps)" % (name, eng, 1e3 * min(ts), st2["steps"]))
+    inst.close()

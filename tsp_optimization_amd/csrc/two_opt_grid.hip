@@ -207,13 +207,17 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     hipStream_t s = t->inst->ctx->stream;
     const double t0 = wall_s();
     const int64_t batch = 64;
+    // launches between two looks at `done`: short descents (a kicked local optimum, a small instance) should not
+    // pay for dozens of launches that find their tour finished, long ones not for many polls
+    int64_t burst = sync ? 8 : batch;
     int64_t queued = 0;
     int status = TSP_OK;
     if (all_done) *all_done = 0;
     launch_arm(t, mode);
     for (;;) {
-        int64_t todo = batch;
-        if (max_steps >= 0) todo = std::min<int64_t>(batch, max_steps - queued);
+        int64_t todo = burst;
+        burst = std::min(batch, burst * 2);
+        if (max_steps >= 0) todo = std::min<int64_t>(todo, max_steps - queued);
         if (todo <= 0) break;
         // A full batch of identical launches is replayed from a captured hipGraph (the kernel arguments
         // never change: the descent is driven by the device-resident control block); partial batches and
