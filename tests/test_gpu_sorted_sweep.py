@@ -204,3 +204,32 @@ def test_sorted_sweep_time_limit_leaves_a_consistent_tour(eng, ctx):
     rc2, s2, o2, st2 = inst.two_opt(s, o, mode=eng.BEST)          # and the descent can be resumed from it
     assert rc2 == 0 and o2 == 75471617.0 and st["sweeps"] + st2["sweeps"] == 1428 + 0
     inst.close()
+
+
+@pytest.mark.parametrize("name,ic", [("att532", 1), ("dsj1000", 1), ("d493", 1), ("d493", 0), ("kroA100", 0), ("rand2000", 1)])
+def test_greedy_spatial_and_dense_kernels_agree_with_the_oracle(eng, ctx, monkeypatch, name, ic):
+    """k_construct_nn (nearest neighbour over the Hilbert groups, one wave per start; packed keys for integer
+    costs, the generic reduction for --fcost) and k_construct_lds (every candidate every step) against greedy()."""
+    xy, wt = load_instance(name)
+    n = len(xy)
+    starts = np.array([0, n // 2, n - 1, 7], dtype=np.int32)
+    exp = [O.greedy(xy, wt, start=int(s0), integer_cost=ic) for s0 in starts]
+    for nn in ("1", "0"):
+        monkeypatch.setenv("TSP_CONSTRUCT_NN", nn)
+        inst = eng.Instance(ctx, xy, wt, ic)
+        succ, obj, _ = inst.construct(eng.GREEDY, starts)
+        inst.close()
+        for b in range(len(starts)):
+            assert (succ[b] == exp[b][1]).all() and obj[b] == exp[b][2], (nn, b)
+
+
+def test_greedy_spatial_kernel_with_coincident_points(eng, ctx):
+    rng = np.random.default_rng(21)
+    xy = rng.integers(0, 15, size=(700, 2)).astype(np.float64)     # heavy ties: the lowest index must win
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    starts = np.arange(0, 700, 97, dtype=np.int32)
+    succ, obj, _ = inst.construct(eng.GREEDY, starts)
+    inst.close()
+    for b, s0 in enumerate(starts):
+        _, es, eo = O.greedy(xy, O.EUC_2D, start=int(s0))
+        assert (succ[b] == es).all() and obj[b] == eo

@@ -179,6 +179,7 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
             lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy;
         }
         const double span = sqrt((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
+        inst->cost_bound = span + 2.0;
         {   // root filter margin: two raw roots (each within r * 2^-23 of r <= span, taken at 2^-22 for slack)
             // + the rounding the exact metric adds to each of the two distances (nint 0.5, ceil/ATT < 1)
             const char *nof = getenv("TSP_NO_FILTER");
@@ -238,7 +239,9 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
             b.x = std::min(b.x, xy[2 * v]); b.y = std::max(b.y, xy[2 * v]);
             b.z = std::min(b.z, xy[2 * v + 1]); b.w = std::max(b.w, xy[2 * v + 1]);
         }
-        inst->ng = ng; inst->n_slots = n_slots; inst->h_gbox = gbox;
+        inst->ng = ng; inst->n_slots = n_slots; inst->h_gbox = gbox; inst->org_x = lox; inst->org_y = loy;
+        inst->h_sinv.assign((size_t)n, 0);
+        for (int k = 0; k < n; ++k) inst->h_sinv[sperm[k]] = k;
         TSP_HIP_TRY(hipMalloc(&inst->d_sperm, sizeof(int) * (size_t)n_slots));
         TSP_HIP_TRY(hipMalloc(&inst->d_gbox, sizeof(double4) * ((size_t)ng + 1)));
         TSP_HIP_TRY(hipMemcpyAsync(inst->d_sperm, sperm.data(), sizeof(int) * (size_t)n_slots, hipMemcpyHostToDevice, ctx->stream));

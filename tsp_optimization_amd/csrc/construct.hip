@@ -250,6 +250,200 @@ __global__ __launch_bounds__(kConsLdsThreads) void k_construct_lds(const double2
     if (tid == 0) { obj[b] = total; status[b] = TSP_OK; }
 }
 
+// ---- k_construct_nn: nearest neighbour over the Hilbert groups ---------------------------------------------------
+// greedy() asks n times for the nearest unvisited node (lowest index among equals, heuristics.c:51).  With the
+// nodes ranked along a Hilbert curve (tsp_dev_inst_create: 64 consecutive ranks = one group with a bounding box)
+// that is a spatial query: find the unvisited group whose box is nearest, evaluate its 64 nodes, then only the
+// groups whose box is not provably farther than the best distance found.  One wave per start and nothing but
+// wave-level reductions: no block barrier in the n-step chain (the 256-thread kernel above spends a step's 4 us
+// at n = 10 000 on 40 candidates per thread and a barrier).  Coordinates (relative to the instance's corner, as
+// floats when they are bounded integers: exact), node ids, the groups' alive masks and boxes live in LDS.
+constexpr int kNnMaxRounds = 4;   // groups per lane: up to 256 groups = 16 384 ranks
+
+// min over the 64 lanes of an unsigned 64-bit key, through DPP row operations (a __shfl_xor is an LDS crossbar
+// round trip per step, and this kernel's steps are nothing but such reductions): xor 1, xor 2, half-row mirror,
+// row mirror inside each row of 16, then lane 15 -> next row, lane 31 -> upper half; lane 63 holds the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_step(unsigned long long v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    v = dpp_min_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_min_step<0x140, 0xf>(v);   // row_mirror
+    v = dpp_min_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <typename CT>
+__host__ __device__ inline size_t nn_lds_bytes(int n_slots, int ng) {
+    return sizeof(CT) * (size_t)n_slots + sizeof(int) * (size_t)n_slots + (sizeof(unsigned long long) + sizeof(double4)) * (size_t)ng + 64;
+}
+
+template <int WT, bool INT, typename CT, bool PACK>
+__global__ __launch_bounds__(64) void k_construct_nn(const double2 *__restrict__ coord, const int *__restrict__ sperm,
+                                                     const double4 *__restrict__ gbox, int n, int ng, int n_slots,
+                                                     double ox, double oy, const int *__restrict__ starts,
+                                                     const int *__restrict__ start_slots, int *__restrict__ succ_all,
+                                                     double *__restrict__ obj, int *__restrict__ status) {
+    constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
+    // a distance is at least the root minus 1/2 when it is rounded to nearest (EUC_2D integer costs), at least the
+    // root otherwise: a group whose box is farther than best + slack cannot hold a node as near as the best
+    constexpr double kRound = (INT && (WT == WT_EUC_2D || WT == WT_EUC_2D_ICOORD)) ? 0.5 : 0.0;
+    extern __shared__ __attribute__((aligned(16))) char nn_smem[];
+    double4 *s_box = reinterpret_cast<double4 *>(nn_smem);
+    unsigned long long *s_alive = reinterpret_cast<unsigned long long *>(s_box + ng);
+    CT *s_xy = reinterpret_cast<CT *>(s_alive + ng);
+    int *s_id = reinterpret_cast<int *>(s_xy + n_slots);
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int start = starts[b];
+    if (start < 0 || start >= n) {
+        if (lane == 0) { status[b] = TSP_WRONG_STARTING_NODE; obj[b] = 0.0; }
+        return;
+    }
+    int *succ = succ_all + (size_t)b * n;
+    for (int g = 0; g < ng; ++g) {
+        const int k = g * 64 + lane;
+        const int v = sperm[k];
+        const double2 c = coord[max(v, 0)];
+        CT q;
+        q.x = (decltype(q.x))(c.x - ox); q.y = (decltype(q.y))(c.y - oy);
+        s_xy[k] = q;
+        s_id[k] = v;
+        const unsigned long long m = __ballot(v >= 0);
+        if (lane == 0) s_alive[g] = m;
+    }
+    for (int g = lane; g < ng; g += 64) {
+        double4 bx = gbox[g];
+        bx.x -= ox; bx.y -= ox; bx.z -= oy; bx.w -= oy;
+        s_box[g] = bx;
+    }
+    __syncthreads();   // one wave: orders the LDS writes above against the reads below
+    int cur_slot = start_slots[b], cur_id = start;
+    if (lane == 0) s_alive[cur_slot >> 6] &= ~(1ull << (cur_slot & 63));
+    __syncthreads();
+    double curx = (double)s_xy[cur_slot].x, cury = (double)s_xy[cur_slot].y;
+    const double sx = curx, sy = cury;
+    double total = 0.0;
+
+    for (int step = 1; step < n; ++step) {
+        // A: the unvisited group whose box is nearest
+        double lb2[kNnMaxRounds];
+        double near2 = DBL_MAX;
+        int near_g = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < kNnMaxRounds; ++r) {
+            const int g = lane + 64 * r;
+            lb2[r] = DBL_MAX;
+            if (g < ng && s_alive[g] != 0ull) {
+                const double4 bx = s_box[g];
+                const double gx = fmax(0.0, fmax(bx.x - curx, curx - bx.y)), gy = fmax(0.0, fmax(bx.z - cury, cury - bx.w));
+                lb2[r] = gx * gx + gy * gy;
+                if (lb2[r] < near2) { near2 = lb2[r]; near_g = g; }
+            }
+        }
+        double bd = DBL_MAX;
+        int bid = 0x7fffffff, bslot = -1;
+        if constexpr (PACK) {
+            // integer costs below 2^31, ids and slots below 2^15: (distance, id, slot) is one 64-bit key and a
+            // reduction one DPP min; a non-negative double orders like its bits
+            const unsigned long long nb = wave_min_u64((unsigned long long)__double_as_longlong(near2));
+            const unsigned long long who = __ballot((unsigned long long)__double_as_longlong(near2) == nb);
+            near_g = __builtin_amdgcn_readlane(near_g, __builtin_ctzll(who));
+            unsigned long long best = ~0ull;
+            auto eval_group = [&](int g) {
+                const int slot = g * 64 + lane;
+                const bool bit = (s_alive[g] >> lane) & 1ull;
+                const CT c = s_xy[slot];
+                const int id = s_id[slot];
+                const double d = dist_xy<WT, INT>(curx, cury, (double)c.x, (double)c.y);
+                const unsigned long long k = ((unsigned long long)(long long)d << 30) | ((unsigned long long)id << 15) | (unsigned)slot;
+                if (bit && k < best) best = k;
+            };
+            eval_group(near_g);
+            const unsigned long long b1 = wave_min_u64(best);
+            const double reach = (double)(b1 >> 30) + kRound;
+            const double thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9;
+#pragma unroll
+            for (int r = 0; r < kNnMaxRounds; ++r) {
+                const int g = lane + 64 * r;
+                unsigned long long cand = __ballot(g != near_g && lb2[r] <= thr2);
+                while (cand) {
+                    const int bit = __builtin_ctzll(cand);
+                    cand &= cand - 1;
+                    eval_group(bit + 64 * r);
+                }
+            }
+            const unsigned long long b2 = wave_min_u64(best);
+            bd = (double)(b2 >> 30); bid = (int)((b2 >> 15) & 0x7fff); bslot = (int)(b2 & 0x7fff);
+        } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o2 = __shfl_xor(near2, off);
+            const int og = __shfl_xor(near_g, off);
+            if (o2 < near2 || (o2 == near2 && og < near_g)) { near2 = o2; near_g = og; }
+        }
+        // B: its nodes; (distance, node id) smallest first == the reference's scan with its strict '<'
+        auto eval_group = [&](int g) {
+            const int slot = g * 64 + lane;
+            const bool bit = (s_alive[g] >> lane) & 1ull;
+            const CT c = s_xy[slot];
+            const int id = s_id[slot];
+            const double d = dist_xy<WT, INT>(curx, cury, (double)c.x, (double)c.y);
+            if (bit && (d < bd || (d == bd && id < bid))) { bd = d; bid = id; bslot = slot; }
+        };
+        auto reduce_best = [&]() {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double od = __shfl_xor(bd, off);
+                const int oi = __shfl_xor(bid, off), os = __shfl_xor(bslot, off);
+                if (od < bd || (od == bd && oi < bid)) { bd = od; bid = oi; bslot = os; }
+            }
+        };
+        eval_group(near_g);
+        reduce_best();
+        // C: every other group that could hold a node as near (ties included: the lower id wins)
+        const double reach = bd + kRound;
+        const double thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9;
+#pragma unroll
+        for (int r = 0; r < kNnMaxRounds; ++r) {
+            const int g = lane + 64 * r;
+            unsigned long long cand = __ballot(g != near_g && lb2[r] <= thr2);
+            while (cand) {
+                const int bit = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                eval_group(bit + 64 * r);
+            }
+        }
+        reduce_best();
+        }
+        // the edge, and the node leaves the candidate set
+        if (lane == 0) {
+            succ[cur_id] = bid;
+            s_alive[bslot >> 6] &= ~(1ull << (bslot & 63));
+        }
+        total += bd;
+        cur_id = bid; cur_slot = bslot;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        curx = (double)s_xy[cur_slot].x; cury = (double)s_xy[cur_slot].y;
+    }
+    if (lane == 0) {
+        succ[cur_id] = start;                                   // heuristics.c:60-61
+        total += dist_xy<WT, INT>(curx, cury, sx, sy);          // :74
+        obj[b] = total; status[b] = TSP_OK;
+    }
+}
+
 // ---- distance matrix ------------------------------------------------------------------------
 // Block = kDmRows rows x 1024 columns.  Each lane keeps the coordinates of its 4 consecutive
 // columns in registers for all rows of the block, computes 4 entries per row and streams them out
@@ -334,11 +528,43 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         TSP_HIP_TRY(hipMalloc(&d_urand, sizeof(double) * (size_t)B * n));
         TSP_HIP_TRY(hipMemcpyAsync(d_urand, urand, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, s));
     }
+    // greedy on a sqrt metric with the Hilbert groups at hand: the spatial kernel, one wave per start
+    bool use_nn = false;
+    int *d_slots = nullptr;
+    {
+        const char *off = getenv("TSP_CONSTRUCT_NN");
+        const bool icoord = inst->wtype == tsp::WT_EUC_2D_ICOORD || inst->wtype == tsp::WT_CEIL_2D_ICOORD || inst->wtype == tsp::WT_ATT_ICOORD;
+        const size_t need = icoord ? nn_lds_bytes<float2>(inst->n_slots, inst->ng) : nn_lds_bytes<double2>(inst->n_slots, inst->ng);
+        use_nn = kind == TSP_CONSTRUCT_GREEDY && inst->d_sperm && !(off && *off == '0') && inst->ng <= 64 * kNnMaxRounds &&
+                 need <= (size_t)158 * 1024;
+        // one 64-bit key per candidate when the costs are integers below 2^31 and ids/slots fit in 15 bits
+        const bool pack = inst->integer_cost && inst->n_slots <= 32768 && inst->cost_bound < 2147483647.0;
+        if (use_nn) {
+            std::vector<int> slots((size_t)B, 0);
+            for (int b = 0; b < B; ++b) if (starts[b] >= 0 && starts[b] < n) slots[b] = inst->h_sinv[starts[b]];
+            TSP_HIP_TRY(hipMalloc(&d_slots, sizeof(int) * (size_t)B));
+            TSP_HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+            TSP_HIP_TRY(hipStreamSynchronize(s));   // `slots` dies with this scope
+            hipError_t e_nn = hipSuccess;
+            TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+                if constexpr (has_root_filter<WTC>()) {
+                    constexpr bool IC = WTC == tsp::WT_EUC_2D_ICOORD || WTC == tsp::WT_CEIL_2D_ICOORD || WTC == tsp::WT_ATT_ICOORD;
+                    using CT = std::conditional_t<IC, float2, double2>;
+                    auto kf = pack ? k_construct_nn<WTC, INTC, CT, true> : k_construct_nn<WTC, INTC, CT, false>;
+                    e_nn = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                    hipLaunchKernelGGL(kf, dim3(B), dim3(64), need, s, inst->d_coord, inst->d_sperm, inst->d_gbox, n, inst->ng,
+                                       inst->n_slots, IC ? inst->org_x : 0.0, IC ? inst->org_y : 0.0, d_starts, d_slots, d_succ,
+                                       d_obj, d_status);
+                }
+            });
+            TSP_HIP_TRY(e_nn);
+        }
+    }
     const char *no_lds = getenv("TSP_CONSTRUCT_GLOBAL");
     const size_t lds_bytes = 4 * (kConsLdsThreads / 64) * sizeof(ConsSlot) + sizeof(double2) * (size_t)n;
     const bool use_lds = !(no_lds && *no_lds == '1') && n <= kConsLdsMaxN && lds_bytes <= (size_t)160 * 1024;
     hipError_t attr_err = hipSuccess;
-    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+    if (!use_nn) TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
         if (use_lds) {
             if (kind == TSP_CONSTRUCT_GRASP) {
                 auto kf = k_construct_lds<WTC, INTC, true>;
@@ -373,7 +599,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         for (int v = 0; v < n; ++v) sp[(size_t)v * succ_stride] = h_succ[(size_t)b * n + v];
     }
     (void)hipFree(d_starts); (void)hipFree(d_status); (void)hipFree(d_obj); (void)hipFree(d_succ);
-    (void)hipFree(d_vis); (void)hipFree(d_urand);
+    (void)hipFree(d_vis); (void)hipFree(d_urand); (void)hipFree(d_slots);
     return (B == 1) ? worst : TSP_OK;
 }
 

@@ -72,6 +72,9 @@ struct tsp_dev_inst {
     double4 *d_gbox = nullptr;
     std::vector<double4> h_gbox;   // host copy (pair table of the sorted sweep)
     int ng = 0, n_slots = 0;
+    double org_x = 0.0, org_y = 0.0;   // min corner of the coordinates
+    double cost_bound = 1e300;         // no distance of the instance exceeds this (bounding-box diagonal + rounding)
+    std::vector<int> h_sinv;           // node -> rank slot
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
 };
 
