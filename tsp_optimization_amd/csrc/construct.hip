@@ -7,6 +7,7 @@
 // final one" (:117-122), i.e. the arg-min over unvisited k < best -- a second, shorter arg-min that
 // is only needed on the ~10 % of steps whose draw is >= GRASP_RAND (:127-128).
 #include "tsp_internal.hpp"
+#include "two_opt_common.hpp"   // wave_min_u64
 
 #include <cfloat>
 
@@ -260,28 +261,7 @@ __global__ __launch_bounds__(kConsLdsThreads) void k_construct_lds(const double2
 // floats when they are bounded integers: exact), node ids, the groups' alive masks and boxes live in LDS.
 constexpr int kNnMaxRounds = 4;   // groups per lane: up to 256 groups = 16 384 ranks
 
-// min over the 64 lanes of an unsigned 64-bit key, through DPP row operations (a __shfl_xor is an LDS crossbar
-// round trip per step, and this kernel's steps are nothing but such reductions): xor 1, xor 2, half-row mirror,
-// row mirror inside each row of 16, then lane 15 -> next row, lane 31 -> upper half; lane 63 holds the result.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned long long dpp_min_step(unsigned long long v) {
-    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-    return o < v ? o : v;
-}
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-    v = dpp_min_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v = dpp_min_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v = dpp_min_step<0x141, 0xf>(v);   // row_half_mirror
-    v = dpp_min_step<0x140, 0xf>(v);   // row_mirror
-    v = dpp_min_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_min_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
+
 
 template <typename CT>
 __host__ __device__ inline size_t nn_lds_bytes(int n_slots, int ng) {

@@ -22,19 +22,58 @@ __device__ __forceinline__ bool better(double d1, u64 k1, double d2, u64 k2) {
     return d1 < d2 || (d1 == d2 && k1 < k2);
 }
 
+// min over the 64 lanes of an unsigned 64-bit key, through DPP row operations (a __shfl_xor is an LDS crossbar
+// round trip per step; the step kernels and the nearest-neighbour construction are chains of such reductions):
+// xor 1, xor 2, half-row mirror, row mirror inside each row of 16, then lane 15 -> next row, lane 31 -> upper half;
+// lane 63 holds the result and hands it to everyone.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_step(unsigned long long v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    v = dpp_min_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_min_step<0x140, 0xf>(v);   // row_mirror
+    v = dpp_min_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_min_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// a double as an unsigned key of the same order (no NaNs here)
+__device__ __forceinline__ u64 ordered_bits(double d) {
+    const u64 b = (u64)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | (1ull << 63));
+}
+__device__ __forceinline__ double from_ordered_bits(u64 k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & ~(1ull << 63)) : ~k));
+}
+
 // BY_DELTA: arg-min of (delta, key); else: min key (first improving pair), delta rides along.
+// Every lane ends up with the winner.
 template <bool BY_DELTA>
 __device__ __forceinline__ void wave_argmin(double &d, u64 &k) {
-    // Almost every wave of a scan has no candidate at all (one move per sweep): one ballot instead of
-    // eighteen cross-lane moves.  A wave with no key keeps (d, kNoKey) in every lane, which is what the
-    // reduction would have produced for the key; callers only use d together with a valid key.
+    // Almost every wave of a scan has no candidate at all (one move per sweep): one ballot and out.  A wave with no
+    // key keeps (d, kNoKey) in every lane, which is what the reduction would have produced for the key; callers
+    // only use d together with a valid key.
     if (!__any(k != kNoKey)) return;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double od = __shfl_xor(d, off);
-        const u64 ok = __shfl_xor(k, off);
-        const bool take = BY_DELTA ? better(od, ok, d, k) : (ok < k);
-        if (take) { d = od; k = ok; }
+    if constexpr (BY_DELTA) {
+        const u64 dk = ordered_bits(d == 0.0 ? 0.0 : d);   // -0.0 and 0.0 are the same delta
+        const u64 md = wave_min_u64(dk);
+        k = wave_min_u64(dk == md ? k : kNoKey);           // among the minimal deltas, the first pair in scan order
+        d = from_ordered_bits(md);
+    } else {
+        const u64 mk = wave_min_u64(k);
+        const int src = __builtin_ctzll(__ballot(k == mk));
+        const int lo = __builtin_amdgcn_readlane(__double2loint(d), src), hi = __builtin_amdgcn_readlane(__double2hiint(d), src);
+        d = __hiloint2double(hi, lo);
+        k = mk;
     }
 }
 

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             constexpr int U = MODE == TSP_2OPT_FIRST ? 1 : 4;
             // batches that hold no column above the rows (or, for the cursor's row alone, above the cursor) are skipped
             const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == ci) ? cj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
+            const bool vote = n - jbase > 2 * kLdsThreads;   // a vote is a barrier: not for two batches
             for (int j0 = jbase + tid; j0 - tid < n; j0 += U * kLdsThreads) {
                 int jj[U], pp[U], sc[U];
                 bool act[U];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     }
                 }
                 if constexpr (MODE == TSP_2OPT_FIRST) {
-                    if (__syncthreads_or(key != kNoKey && key_i(key) == rb)) break;
+                    if (vote && __syncthreads_or(key != kNoKey && key_i(key) == rb)) break;
                 }
             }
         }
