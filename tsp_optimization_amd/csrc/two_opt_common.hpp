@@ -92,13 +92,45 @@ __device__ __forceinline__ void block_argmin(double &d, u64 &k, double *s_d, u64
     }
 }
 
+// sum over the 64 lanes (same DPP walk as wave_min_u64; a lane outside a step's row mask adds nothing)
+template <typename T, int CTRL, int ROW_MASK>
+__device__ __forceinline__ T dpp_add_step(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit payloads");
+    if constexpr (sizeof(T) == 4) {
+        int b;
+        __builtin_memcpy(&b, &v, 4);
+        const int o = __builtin_amdgcn_update_dpp(0, b, CTRL, ROW_MASK, 0xf, false);
+        T t;
+        __builtin_memcpy(&t, &o, 4);
+        return v + t;
+    } else {
+        unsigned long long b;
+        __builtin_memcpy(&b, &v, 8);
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        T t;
+        __builtin_memcpy(&t, &o, 8);
+        return v + t;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_to_lane63(T v) {
+    v = dpp_add_step<T, 0xB1, 0xf>(v);
+    v = dpp_add_step<T, 0x4E, 0xf>(v);
+    v = dpp_add_step<T, 0x141, 0xf>(v);
+    v = dpp_add_step<T, 0x140, 0xf>(v);
+    v = dpp_add_step<T, 0x142, 0xa>(v);
+    v = dpp_add_step<T, 0x143, 0xc>(v);
+    return v;   // complete in lane 63 only
+}
+
 template <typename T>
 __device__ __forceinline__ T block_sum(T v, T *scratch /* >= blockDim/64 */) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    v = wave_sum_to_lane63(v);
     const int tid = threadIdx.x;
     __syncthreads();
-    if ((tid & 63) == 0) scratch[tid >> 6] = v;
+    if ((tid & 63) == 63) scratch[tid >> 6] = v;
     __syncthreads();
     T tot = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += scratch[w];

@@ -54,20 +54,17 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     // `active` of them take a ticket, and block `widx` carries out slices widx, widx + active, ... of the pending
     // move -- only ticket holders touch the other copy, so all of it is written before the last block moves on.
     const int tile_rows = (row_hi - row_lo + rpb - 1) / rpb;
-    __shared__ int s_active, s_widx, s_rowblocks;
-    if (tid < 64) {
-        const int mine = tid < tile_rows ? gx - skipped_in_tile_row(row_lo + tid * rpb, gx, TJ) : 0;
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t2 = __shfl_up(incl, off); if (tid >= off) incl += t2; }
-        if (tid == (int)blockIdx.y) { s_widx = incl - mine + ((int)blockIdx.x - skipped_in_tile_row(r0, gx, TJ)); s_rowblocks = mine; }
-        if (tid == 63) s_active = incl;
+    int active = 0, widx = 0, rowblocks = 0;   // wave-uniform: a scalar loop over the (few) tile rows
+    for (int by = 0; by < tile_rows; ++by) {
+        const int mine = gx - skipped_in_tile_row(row_lo + by * rpb, gx, TJ);
+        if (by < (int)blockIdx.y) widx += mine;
+        if (by == (int)blockIdx.y) rowblocks = mine;
+        active += mine;
     }
-    __syncthreads();
-    const int active = s_active;
+    widx += (int)blockIdx.x - skipped_in_tile_row(r0, gx, TJ);
     if (mv.L > 0) {
         int *o_new = (st->parity ? a.orders : a.orders2) + base, *p_new = (st->parity ? a.poss : a.poss2) + base;
-        for (int k = s_widx * kScanThreads + tid; k < n; k += active * kScanThreads) {
+        for (int k = widx * kScanThreads + tid; k < n; k += active * kScanThreads) {
             const int v = mv.node_at(k);
             o_new[k] = v;
             p_new[v] = k;
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         // one word are served one after the other
         gi32 *rt = (gi32 *)(a.cl_tickets + ((size_t)tour * 64 + blockIdx.y) * 64);
         s_last = 0;
-        if (__hip_atomic_fetch_add(rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == s_rowblocks) {
+        if (__hip_atomic_fetch_add(rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == rowblocks) {
             __hip_atomic_store(rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int old = __hip_atomic_fetch_add((gi32 *)(a.tickets + tour), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last = (old + 1 == tile_rows);

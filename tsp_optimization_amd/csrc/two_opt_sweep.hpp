@@ -49,10 +49,9 @@ __global__ __launch_bounds__(kScanThreads) void k_move_recs(const double2 *__res
         r.x = r.y = r.xs = r.ys = 1e30; r.ds = 0.0; r.succ = -1; r.id = -1;
     }
     recs[(size_t)tour * n_slots + k] = r;
-    double m = r.ds;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) gmax[(size_t)tour * (ng + 1) + (k >> 6)] = m;
+    // the group's longest edge: lengths are >= 0, so they order like their bits and max = ~min(~bits)
+    const u64 mb = ~wave_min_u64(~(u64)__double_as_longlong(r.ds));
+    if ((threadIdx.x & 63) == 0) gmax[(size_t)tour * (ng + 1) + (k >> 6)] = __longlong_as_double((long long)mb);
 }
 
 // End of a run through the sorted sweep: bring the tour back into the first copy of order/pos, where every other
