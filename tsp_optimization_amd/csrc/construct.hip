@@ -26,14 +26,9 @@ struct ArgMin {
 __device__ __forceinline__ bool lt(const ArgMin &a, const ArgMin &b) { return a.d < b.d || (a.d == b.d && a.k < b.k); }
 
 // block-wide (d, k) lexicographic minimum; k == INT_MAX means "none"
+__device__ __forceinline__ ArgMin wave_argmin_dk(ArgMin v);
 __device__ __forceinline__ ArgMin block_argmin(ArgMin v, double *s_d, int *s_k) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        ArgMin o;
-        o.d = __shfl_xor(v.d, off);
-        o.k = __shfl_xor(v.k, off);
-        if (lt(o, v)) v = o;
-    }
+    v = wave_argmin_dk(v);
     const int tid = threadIdx.x;
     __syncthreads();
     if ((tid & 63) == 0) { s_d[tid >> 6] = v.d; s_k[tid >> 6] = v.k; }
@@ -132,15 +127,18 @@ constexpr int kConsLdsThreads = 256;
 constexpr int kConsLdsMaxN = 64 * kConsLdsThreads;
 struct alignas(16) ConsSlot { double d, x, y; int k; int pad; };
 
+// (d, k) minimum of the wave in every lane: distances are >= 0 (or DBL_MAX), so they order like their bits
+__device__ __forceinline__ ArgMin wave_argmin_dk(ArgMin v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v.d);
+    const unsigned long long md = wave_min_u64(bits);
+    const unsigned long long mk = wave_min_u64(bits == md ? (unsigned long long)(unsigned)v.k : ~0ull);
+    ArgMin r;
+    r.d = __longlong_as_double((long long)md); r.k = (int)(unsigned)mk;
+    return r;
+}
+
 __device__ __forceinline__ ConsSlot cons_argmin(ArgMin mine, double mx, double my, ConsSlot *table) {
-    ArgMin w = mine;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        ArgMin o;
-        o.d = __shfl_xor(w.d, off);
-        o.k = __shfl_xor(w.k, off);
-        if (lt(o, w)) w = o;
-    }
+    const ArgMin w = wave_argmin_dk(mine);
     const int tid = threadIdx.x;
     if (mine.k == w.k && (w.k != 0x7fffffff || (tid & 63) == 0)) {  // the winner's lane (lane 0 if the wave has none)
         ConsSlot sl;
