@@ -10,12 +10,12 @@ namespace tsp {
 // ---- first improvement (alg_2opt), second form: k_first ------------------------------------------------------
 // Same decisions as k_step<FIRST> (first improving pair after the cursor in (i<j) order, heuristics.c:452-486),
 // three things done differently, all about the latency of a step:
-//  * the grid is fixed and small (gy tile rows); a block takes ceil(chunk / gy) rows, so the 32-row chunk that
-//    follows every hit is spread over the whole chip one row per block instead of 8 rows on a few CUs, and no
-//    launch dispatches thousands of blocks that return at once;
-//  * the move is carried out by the NEXT launch, out of place, by all blocks (MoveView, as in k_move_recs): the
-//    scan reads the tour through the closed form of the pending reversal, the last block only notes the move;
-//  * the ticket counts up to a number every block works out for itself (no count left behind by the apply).
+//  * the grid is fixed and small (gy = 8 tile rows by 512 columns for one tour); a block takes ceil(chunk / gy) rows.
+//    No launch dispatches thousands of blocks that return at once, and -- arrivals on one word are served one
+//    after the other, ~12 ns each -- few blocks take tickets, on two levels (per tile row, then per tour);
+//  * the move is carried out by the NEXT launch, out of place, by the working blocks (MoveView, as in k_move_recs):
+//    the scan reads the tour through the closed form of the pending reversal, the last block only notes the move;
+//  * two control-block slots per tour (see the kernel): a launch never writes what its own blocks may still read.
 template <int WT, bool INT>
 __device__ __forceinline__ NodeRec load_node_view(const double2 *coord, const MoveView &mv, int n, int v) {
     int q = mv.pos_of(v) + 1;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     const int r1 = min(r0 + rpb, row_hi);
     const int c0 = (int)blockIdx.x * TJ;
     if (c0 + TJ - 1 <= r0) return;            // every column <= every row: nothing with j > i, no ticket
-    // The working blocks of this step number themselves (tile rows first; gy <= 64, one lane per tile row):
+    // The working blocks of this step number themselves (tile rows first):
     // `active` of them take a ticket, and block `widx` carries out slices widx, widx + active, ... of the pending
     // move -- only ticket holders touch the other copy, so all of it is written before the last block moves on.
     const int tile_rows = (row_hi - row_lo + rpb - 1) / rpb;

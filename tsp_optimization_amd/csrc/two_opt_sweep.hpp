@@ -108,16 +108,16 @@ constexpr int kSweepRows = 16;        // rows of one unit of wave work (64 / kSw
 constexpr int kSweepStage = 8;        // group pairs whose records a block holds in LDS at a time (6 KB each)
 constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are processed in further passes)
 
-// k_sweep.  Blocks come in clusters of kSweepCluster.  Cluster q tests the group pairs t = q, q + Q, q + 2Q, ...
-// (row group r against column group c >= r; c == r: the pairs inside the group) with the groups' boxes and longest
-// edges -- one test per thread and round, every block of the cluster the same tests, so that all of them see the
-// same ordered survivor list and block j keeps entries j, j + C, ...: the survivors of a sweep are very unevenly
-// spread over the row groups (a group that holds one long edge survives against everything), the strided sample
-// plus the deal spreads them evenly over the chip without a queue or a second launch.
-// A wave then takes half a surviving group pair at a time: rows 32h .. 32h+31 of r against one column of c per
-// lane.  The 32 row records are staged in the wave's own LDS strip and read back as wave-uniform broadcasts; the
-// waves of a block share nothing until the block's arg-min.  Rows go four at a time so that the LDS reads and the
-// fp64 chains of different rows overlap.
+// k_sweep.  Blocks come in clusters of kSweepCluster.  The group pairs (row group r, column group c >= r; c == r: the
+// pairs inside the group) are listed by box distance in a host-built table and dealt to the clusters in turn; every
+// block of a cluster runs the same box tests, one per thread and round, so all of them see the same ordered survivor
+// list and block j keeps ranks j, j + C, ...  The survivors of a sweep are very unevenly spread (a group that holds
+// one long edge survives against everything, near pairs always survive and cost the most): the table plus the deal
+// spreads them evenly over the chip without a queue or a second launch.
+// The 128 records of each of a block's pairs are fetched in one burst into LDS; a wave takes kSweepRows rows of a
+// pair at a time against one column per lane: rows that cannot reach the column box are dropped by one ballot, the
+// others go four per step with their x, y, edge length broadcast out of registers (v_readlane), so the common path
+// (tier 0) touches neither memory nor LDS.  The waves of a block share nothing until the block's arg-min.
 template <int WT, bool INT>
 __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {   // 3 waves per SIMD: 768 blocks resident
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
