@@ -13,7 +13,7 @@ B.LIB_DIR = os.path.join(R, 'tsp_optimization_amd', 'lib_diag')
 from tsp_optimization_amd import engine as E
 from helpers import load_instance
 names = ["start->prologue done", "row loop", "block argmin", "publish+drain", "ticket atomic+barrier",
-         "read partials+argmin", "pos + adj count + barrier", "swaps", "cost/next-active/state"]
+         "read partials+argmin", "pos + adj count + barrier", "swaps / (k_first: control block)", "cost/next-active/state"]
 ctx = E.Context(0)
 xy, wt = load_instance('rand10000')
 inst = E.Instance(ctx, xy, wt, 1)

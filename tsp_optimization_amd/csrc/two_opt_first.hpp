@@ -33,6 +33,10 @@ template <int WT, bool INT, int RJ>
 __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     constexpr int TJ = kScanThreads * RJ;
     constexpr bool FILTER = has_root_filter<WT>();
+#ifdef TSP_STAMPS
+    __shared__ unsigned long long stamps[16];
+#endif
+    TSP_STAMP(0);
     const int tour = blockIdx.z, n = a.n, tid = threadIdx.x;
     // Two control blocks per tour: this launch reads slot a.slot, which nobody writes while it runs (a block
     // dispatched late must not mistake the next step's cursor for its own), and its last block writes the other.
@@ -82,6 +86,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         if (jc[k] >= n) jc[k] = -1;  // never > i
     }
     __syncthreads();
+    TSP_STAMP(1);
 
     double bd = 0.0;
     int bi = -1, bj = -1;
@@ -107,16 +112,19 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         if (__any(bi >= 0)) break;  // later rows only hold later pairs
     }
 
+    TSP_STAMP(2);
     u64 key = make_key(bi, bj);
     __shared__ double s_d[kScanThreads / 64];
     __shared__ u64 s_k[kScanThreads / 64];
     __shared__ long long s_ll[kScanThreads / 64];
     __shared__ int s_last;
     block_argmin<false>(bd, key, s_d, s_k);
+    TSP_STAMP(3);
     const Partial *part = a.partials + (size_t)tour * a.partial_per_tour;
     if (tid == 0) {
         publish_partial(a.partials + (size_t)tour * a.partial_per_tour + (size_t)blockIdx.y * gx + blockIdx.x, bd, key_i(key), key_j(key));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
+        TSP_STAMP(4);
         // arrivals per tile row first (one word per row, 256 B apart), then the rows on the tour's word: arrivals on
         // one word are served one after the other
         gi32 *rt = (gi32 *)(a.cl_tickets + ((size_t)tour * 64 + blockIdx.y) * 64);
@@ -130,6 +138,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
+    TSP_STAMP(5);
 
     // ---- last block of the step: winner, counters, cursor, the move noted for the next launch
     const int nslots = tile_rows * gx;
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         }
     }
     block_argmin<false>(bd, key, s_d, s_k);
+    TSP_STAMP(6);
     const bool found = key != kNoKey;
     const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
     int pa = 0, pb = 0, L = 0;
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         }
         adj = block_sum<long long>(c, s_ll);
     }
+    TSP_STAMP(7);
     if (tid == 0) {
         int done = 0, n_ci = 0, n_cj = 0, n_chunk = st->chunk_rows, sweep_end = 0;
         double obj = st->obj, seen = st->seen_cost;
@@ -204,6 +215,11 @@ __global__ __launch_bounds__(kScanThreads) void k_first(const StepArgs a) {
         // finished: later launches alternate between the slots and must find `done` in both (a block of this
         // launch that reads it now returns, as it would have anyway: every working block is past its ticket)
         if (done) *const_cast<TourState *>(st) = z;
+#ifdef TSP_STAMPS
+        stamps[8] = wall_clock64(); stamps[9] = stamps[8];
+        for (int k = 1; k < 10; ++k) atomicAdd(&g_stamp_sum[k], stamps[k] - stamps[k - 1]);
+        atomicAdd(&g_stamp_n, 1ull);
+#endif
     }
 }
 
