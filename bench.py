@@ -230,7 +230,7 @@ def main():
             "kernel": "tsp::k_sweep<EUC_2D integer-coordinate variant> (one best-improvement sweep of n=10000 + "
                       "choice of the move), preceded in every launch by tsp::k_move_recs (carries out the previous "
                       "move, rebuilds the per-node records); kernel_ms is the HIP-event time of the pair, back to "
-                      "back, at the start tour (rocprof means: profiles/r01_kernel_stats.csv)",
+                      "back, over 50 further sweeps of the same descent right after the timed region (rocprof means: profiles/r01_kernel_stats.csv)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": ms, "evals_per_launch": evals_per_launch,
