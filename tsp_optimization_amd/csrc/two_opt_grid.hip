@@ -68,7 +68,7 @@ int env_int(const char *name, int dflt);
 // BEST sweeps of this handle go through k_move_recs + k_sweep (no tabu list, metric with the new-edge bound)
 bool sorted_sweep(const tsp_dev_tours *t) {
     return t->inst->d_sperm && t->d_gmax && t->d_order2 && t->n >= t->sorted_min_n && t->inst->prune_margin < 1e299 &&
-           t->inst->ng < 65535;   // k_sweep packs (r, c) into one int and counts group pairs in 31 bits
+           t->inst->ng <= 32768;   // k_sweep packs (r, c) into one int and counts group pairs (ng (ng + 1) / 2) in an int
 }
 
 // After sorted sweeps: pending move carried out, tour back in the first copy of order/pos.
@@ -333,7 +333,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
         cl_words = std::max(cl_words, (size_t)B * (t->sweep_blocks / kSweepCluster) * 64);
         const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
-        if (npairs <= (1ll << 24) && inst->ng < 65535 && env_int("TSP_SWEEP_TABLE", 1)) {
+        if (npairs <= (1ll << 24) && inst->ng <= 32768 && env_int("TSP_SWEEP_TABLE", 1)) {
             // group pairs by box distance, dealt to the clusters in turn (see k_sweep)
             const int ng = inst->ng, Q = t->sweep_blocks / kSweepCluster;
             const long long ntests = (npairs + Q - 1) / Q;
