@@ -233,3 +233,17 @@ def test_greedy_spatial_kernel_with_coincident_points(eng, ctx):
     for b, s0 in enumerate(starts):
         _, es, eo = O.greedy(xy, O.EUC_2D, start=int(s0))
         assert (succ[b] == es).all() and obj[b] == eo
+
+
+@pytest.mark.parametrize("ic", [1, 0])
+def test_greedy_large_instance_kernel_matches_the_oracle(eng, ctx, ic):
+    """n = 17 000 does not fit in LDS: k_construct_nn_big (coordinates in L2, supergroups) against greedy();
+    integer costs use the packed keys, --fcost the generic reduction."""
+    rng = np.random.default_rng(17)
+    xy = rng.integers(0, 400000, size=(17000, 2)).astype(np.float64) if ic else rng.uniform(0, 4e5, size=(17000, 2))
+    inst = eng.Instance(ctx, xy, O.EUC_2D, ic)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([123, 16999], dtype=np.int32))
+    inst.close()
+    for b, s0 in enumerate((123, 16999)):
+        _, es, eo = O.greedy(xy, O.EUC_2D, start=s0, integer_cost=ic)
+        assert (succ[b] == es).all() and obj[b] == eo

@@ -259,7 +259,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     (void)hipStreamSynchronize(inst->ctx->stream);
     if (inst->scratch1) tsp_dev_tours_destroy(inst->scratch1);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
-    (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox);
+    (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy);
     delete inst;
 }
 

@@ -422,6 +422,153 @@ __global__ __launch_bounds__(64) void k_construct_nn(const double2 *__restrict__
     }
 }
 
+// ---- k_construct_nn_big: the same queries for instances that do not fit in LDS (up to 262 144 nodes) ----------
+// Coordinates and ids in rank order stay in HBM/L2 (static per instance); LDS holds what changes or is read every
+// step: the groups' alive masks and their boxes as floats rounded outward.  One more level keeps a step short:
+// 64 groups form a supergroup (one per lane, box and live-node count in registers), a query looks at the nearest
+// live supergroup's groups first and afterwards only at supergroups, then groups, within reach of the best found.
+template <typename CT>
+__global__ void k_sorted_xy(const double2 *__restrict__ coord, const int *__restrict__ sperm, CT *__restrict__ sxy,
+                            int n_slots, double ox, double oy) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const int v = sperm[k];
+    const double2 c = coord[max(v, 0)];
+    CT q;
+    q.x = (decltype(q.x))(c.x - ox); q.y = (decltype(q.y))(c.y - oy);
+    sxy[k] = q;
+}
+
+template <int WT, bool INT, typename CT, bool PACK>
+__global__ __launch_bounds__(64) void k_construct_nn_big(const CT *__restrict__ sxy, const int *__restrict__ sperm,
+                                                         const double4 *__restrict__ gbox, int n, int ng, double ox, double oy,
+                                                         const int *__restrict__ starts, const int *__restrict__ start_slots,
+                                                         int *__restrict__ succ_all, double *__restrict__ obj,
+                                                         int *__restrict__ status) {
+    constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
+    constexpr double kRound = (INT && (WT == WT_EUC_2D || WT == WT_EUC_2D_ICOORD)) ? 0.5 : 0.0;
+    extern __shared__ __attribute__((aligned(16))) char nn_smem[];
+    float4 *s_box = reinterpret_cast<float4 *>(nn_smem);                       // {min x, max x, min y, max y}, outward
+    unsigned long long *s_alive = reinterpret_cast<unsigned long long *>(s_box + ng);
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int start = starts[b];
+    if (start < 0 || start >= n) {
+        if (lane == 0) { status[b] = TSP_WRONG_STARTING_NODE; obj[b] = 0.0; }
+        return;
+    }
+    int *succ = succ_all + (size_t)b * n;
+    const int nsg = (ng + 63) / 64;   // <= 64: one supergroup per lane
+    for (int g = lane; g < ng; g += 64) {
+        const double4 bx = gbox[g];
+        s_box[g] = make_float4(__double2float_rd(bx.x - ox), __double2float_ru(bx.y - ox), __double2float_rd(bx.z - oy),
+                               __double2float_ru(bx.w - oy));
+    }
+    for (int g = 0; g < ng; ++g) {
+        const unsigned long long m = __ballot(sperm[g * 64 + lane] >= 0);
+        if (lane == 0) s_alive[g] = m;
+    }
+    __syncthreads();
+    // the lane's supergroup: box and number of live nodes
+    float sb0 = 3.0e38f, sb1 = -3.0e38f, sb2 = 3.0e38f, sb3 = -3.0e38f;
+    int live = 0;
+    if (lane < nsg) {
+        for (int g = lane * 64; g < min(ng, lane * 64 + 64); ++g) {
+            const float4 bx = s_box[g];
+            sb0 = fminf(sb0, bx.x); sb1 = fmaxf(sb1, bx.y); sb2 = fminf(sb2, bx.z); sb3 = fmaxf(sb3, bx.w);
+            live += __popcll(s_alive[g]);
+        }
+    }
+    int cur_slot = start_slots[b], cur_id = start;
+    if (lane == 0) s_alive[cur_slot >> 6] &= ~(1ull << (cur_slot & 63));
+    if (lane == (cur_slot >> 12)) live -= 1;
+    __syncthreads();
+    double curx = (double)sxy[cur_slot].x, cury = (double)sxy[cur_slot].y;
+    const double sx = curx, sy = cury;
+    double total = 0.0;
+
+    auto box_lb2 = [&](float m0, float m1, float m2, float m3) {
+        const double gx = fmax(0.0, fmax((double)m0 - curx, curx - (double)m1)), gy = fmax(0.0, fmax((double)m2 - cury, cury - (double)m3));
+        return gx * gx + gy * gy;
+    };
+    for (int step = 1; step < n; ++step) {
+        // A: nearest live supergroup, then its nearest live group
+        const double slb2 = (lane < nsg && live > 0) ? box_lb2(sb0, sb1, sb2, sb3) : DBL_MAX;
+        const u64 smin = wave_min_u64((u64)__double_as_longlong(slb2));
+        const int S0 = __builtin_ctzll(__ballot((u64)__double_as_longlong(slb2) == smin));
+        double glb2 = DBL_MAX;
+        {
+            const int g = S0 * 64 + lane;
+            if (g < ng && s_alive[g] != 0ull) { const float4 bx = s_box[g]; glb2 = box_lb2(bx.x, bx.y, bx.z, bx.w); }
+        }
+        const u64 gmin = wave_min_u64((u64)__double_as_longlong(glb2));
+        const int g0 = S0 * 64 + __builtin_ctzll(__ballot((u64)__double_as_longlong(glb2) == gmin));
+        // B / C: (distance, id) smallest first == the reference's scan with its strict '<'
+        double bd = DBL_MAX;
+        int bid = 0x7fffffff, bslot = -1;
+        u64 best = ~0ull;
+        auto eval_group = [&](int g) {
+            const int slot = g * 64 + lane;
+            const bool bit = (s_alive[g] >> lane) & 1ull;
+            const CT c = sxy[slot];
+            const int id = sperm[slot];
+            const double d = dist_xy<WT, INT>(curx, cury, (double)c.x, (double)c.y);
+            if constexpr (PACK) {
+                const u64 k = ((u64)(long long)d << 36) | ((u64)(unsigned)id << 18) | (unsigned)slot;
+                if (bit && k < best) best = k;
+            } else {
+                if (bit && (d < bd || (d == bd && id < bid))) { bd = d; bid = id; bslot = slot; }
+            }
+        };
+        auto reduce_best = [&]() {
+            if constexpr (PACK) {
+                const u64 w = wave_min_u64(best);
+                bd = (double)(w >> 36); bid = (int)((w >> 18) & 0x3ffff); bslot = (int)(w & 0x3ffff);
+            } else {
+                const u64 md = wave_min_u64((u64)__double_as_longlong(bd));
+                const u64 mi = wave_min_u64((u64)__double_as_longlong(bd) == md ? (u64)(unsigned)bid : ~0ull);
+                const int src = __builtin_ctzll(__ballot((u64)__double_as_longlong(bd) == md && (u64)(unsigned)bid == mi));
+                bd = __longlong_as_double((long long)md); bid = (int)(unsigned)mi; bslot = __builtin_amdgcn_readlane(bslot, src);
+            }
+        };
+        eval_group(g0);
+        reduce_best();
+        const double reach = bd + kRound;
+        const double thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9;
+        u64 scand = __ballot(slb2 <= thr2);
+        while (scand) {
+            const int S = __builtin_ctzll(scand);
+            scand &= scand - 1;
+            const int g = S * 64 + lane;
+            bool in = false;
+            if (g < ng && g != g0 && s_alive[g] != 0ull) { const float4 bx = s_box[g]; in = box_lb2(bx.x, bx.y, bx.z, bx.w) <= thr2; }
+            u64 cand = __ballot(in);
+            while (cand) {
+                const int bit = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                eval_group(S * 64 + bit);
+            }
+        }
+        reduce_best();
+        if (lane == 0) {
+            succ[cur_id] = bid;
+            s_alive[bslot >> 6] &= ~(1ull << (bslot & 63));
+        }
+        if (lane == (bslot >> 12)) live -= 1;
+        total += bd;
+        cur_id = bid; cur_slot = bslot;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const CT cc = sxy[cur_slot];
+        curx = (double)cc.x; cury = (double)cc.y;
+    }
+    if (lane == 0) {
+        succ[cur_id] = start;                                   // heuristics.c:60-61
+        total += dist_xy<WT, INT>(curx, cury, sx, sy);          // :74
+        obj[b] = total; status[b] = TSP_OK;
+    }
+}
+
 // ---- distance matrix ------------------------------------------------------------------------
 // Block = kDmRows rows x 1024 columns.  Each lane keeps the coordinates of its 4 consecutive
 // columns in registers for all rows of the block, computes 4 entries per row and streams them out
@@ -513,10 +660,14 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         const char *off = getenv("TSP_CONSTRUCT_NN");
         const bool icoord = inst->wtype == tsp::WT_EUC_2D_ICOORD || inst->wtype == tsp::WT_CEIL_2D_ICOORD || inst->wtype == tsp::WT_ATT_ICOORD;
         const size_t need = icoord ? nn_lds_bytes<float2>(inst->n_slots, inst->ng) : nn_lds_bytes<double2>(inst->n_slots, inst->ng);
-        use_nn = kind == TSP_CONSTRUCT_GREEDY && inst->d_sperm && !(off && *off == '0') && inst->ng <= 64 * kNnMaxRounds &&
-                 need <= (size_t)158 * 1024;
-        // one 64-bit key per candidate when the costs are integers below 2^31 and ids/slots fit in 15 bits
-        const bool pack = inst->integer_cost && inst->n_slots <= 32768 && inst->cost_bound < 2147483647.0;
+        const bool small = inst->ng <= 64 * kNnMaxRounds && need <= (size_t)158 * 1024;
+        // larger instances: coordinates stay in HBM/L2, LDS holds the alive masks and float boxes (k_construct_nn_big)
+        const size_t need_big = (sizeof(float4) + sizeof(unsigned long long)) * (size_t)inst->ng + 64;
+        const bool big = !small && inst->ng <= 4096 && need_big <= (size_t)158 * 1024;
+        use_nn = kind == TSP_CONSTRUCT_GREEDY && inst->d_sperm && !(off && *off == '0') && (small || big);
+        // one 64-bit key per candidate when the costs are integers and ids/slots fit their fields
+        const bool pack = inst->integer_cost && (small ? (inst->n_slots <= 32768 && inst->cost_bound < 2147483647.0)
+                                                       : (inst->n_slots <= 262144 && inst->cost_bound < 268435455.0));
         if (use_nn) {
             std::vector<int> slots((size_t)B, 0);
             for (int b = 0; b < B; ++b) if (starts[b] >= 0 && starts[b] < n) slots[b] = inst->h_sinv[starts[b]];
@@ -528,11 +679,26 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
                 if constexpr (has_root_filter<WTC>()) {
                     constexpr bool IC = WTC == tsp::WT_EUC_2D_ICOORD || WTC == tsp::WT_CEIL_2D_ICOORD || WTC == tsp::WT_ATT_ICOORD;
                     using CT = std::conditional_t<IC, float2, double2>;
-                    auto kf = pack ? k_construct_nn<WTC, INTC, CT, true> : k_construct_nn<WTC, INTC, CT, false>;
-                    e_nn = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
-                    hipLaunchKernelGGL(kf, dim3(B), dim3(64), need, s, inst->d_coord, inst->d_sperm, inst->d_gbox, n, inst->ng,
-                                       inst->n_slots, IC ? inst->org_x : 0.0, IC ? inst->org_y : 0.0, d_starts, d_slots, d_succ,
-                                       d_obj, d_status);
+                    const double ox = IC ? inst->org_x : 0.0, oy = IC ? inst->org_y : 0.0;
+                    if (small) {
+                        auto kf = pack ? k_construct_nn<WTC, INTC, CT, true> : k_construct_nn<WTC, INTC, CT, false>;
+                        e_nn = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                        hipLaunchKernelGGL(kf, dim3(B), dim3(64), need, s, inst->d_coord, inst->d_sperm, inst->d_gbox, n, inst->ng,
+                                           inst->n_slots, ox, oy, d_starts, d_slots, d_succ, d_obj, d_status);
+                    } else {
+                        if (!inst->d_sxy) {   // rank-ordered coordinates, once per instance
+                            e_nn = hipMalloc(&inst->d_sxy, sizeof(CT) * (size_t)inst->n_slots);
+                            if (e_nn == hipSuccess)
+                                hipLaunchKernelGGL((k_sorted_xy<CT>), dim3((inst->n_slots + 255) / 256), dim3(256), 0, s, inst->d_coord,
+                                                   inst->d_sperm, (CT *)inst->d_sxy, inst->n_slots, ox, oy);
+                        }
+                        if (e_nn == hipSuccess) {
+                            auto kf = pack ? k_construct_nn_big<WTC, INTC, CT, true> : k_construct_nn_big<WTC, INTC, CT, false>;
+                            e_nn = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need_big);
+                            hipLaunchKernelGGL(kf, dim3(B), dim3(64), need_big, s, (const CT *)inst->d_sxy, inst->d_sperm, inst->d_gbox, n,
+                                               inst->ng, ox, oy, d_starts, d_slots, d_succ, d_obj, d_status);
+                        }
+                    }
                 }
             });
             TSP_HIP_TRY(e_nn);
