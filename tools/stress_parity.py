@@ -1,0 +1,44 @@
+"""Randomised parity sweep (one-off, run through gpurun): random sizes around the tile / group / batch boundaries,
+random metrics and cost modes, random tours; both rules, forced sorted sweep, both construction kernels -- all
+against the oracle.  Prints the first mismatch and exits non-zero."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+import numpy as np
+os.environ["TSP_SORTED_MIN_N"] = "0"
+from tsp_optimization_amd import engine as E
+from helpers import random_tour
+from oracle import oracle as O
+ctx = E.Context(0)
+rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
+sizes = [4, 5, 6, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640, 700, 1023, 1024, 1025]
+cases = int(os.environ.get("CASES", "60"))
+bad = 0
+for c in range(cases):
+    n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(4, 900))
+    wt = int(rng.choice([O.EUC_2D, O.ATT, O.CEIL_2D, O.MAN_2D, O.MAX_2D]))
+    ic = int(rng.random() < 0.75)
+    if rng.random() < 0.5: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
+    else: xy = rng.uniform(-5000, 5000, size=(n, 2))
+    if wt == O.CEIL_2D: ic = 1
+    inst = E.Instance(ctx, xy, wt, ic)
+    s0 = int(rng.integers(0, n))
+    succ, obj, _ = inst.construct(E.GREEDY, np.array([s0], dtype=np.int32))
+    _, es, eo = O.greedy(xy, wt, start=s0, integer_cost=ic)
+    ok = (succ[0] == es).all() and obj[0] == eo
+    tour = random_tour(n, rng) if rng.random() < 0.5 else es
+    cost = O.succ_cost(xy, wt, tour, integer_cost=ic)
+    if n <= 300:   # the oracle's best-improvement descent from a random tour is O(n^3)
+        rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=1)
+        _, bs, bo, bst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic)
+        ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+    rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
+    _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
+    ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+    inst.close()
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: n %d wt %d ic %d" % (c, n, wt, ic))
+        break
+print("cases %d, mismatches %d" % (c + 1, bad))
+sys.exit(1 if bad else 0)
