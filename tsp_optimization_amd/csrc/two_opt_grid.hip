@@ -3,11 +3,17 @@
 // Tour state in HBM is two int arrays per tour, order[p] (node at tour position p) and pos[v]
 // (position of node v); succ(v) = order[pos[v]+1].  Coordinates are per instance.
 //
-// One step = ONE launch of k_step: every block evaluates its tile of (i<j) node pairs against the
-// current tour and publishes one candidate; the block that arrives last (per-tour countdown
-// ticket) picks the winner, reverses the tour segment and advances the tour's control block for
-// the next launch.  The host only queues steps and polls `done`; every decision of the
-// reference's loops is taken on the device:
+// One step of a descent = one launch (two for the sorted sweep); the host only queues steps and polls `done`,
+// every decision of the reference's loops is taken on the device, through a per-tour control block.  Four kernels
+// implement a step (headers of the same name stem):
+//   two_opt_tiled.hpp  k_step      every pair of the scanned range visited, tile by tile; the block that arrives
+//                                  last picks the winner and reverses the segment.  Tabu runs, non-sqrt metrics,
+//                                  best improvement below TSP_SORTED_MIN_N nodes, first improvement as TSP_FIRST_V1.
+//   two_opt_sweep.hpp  k_move_recs + k_sweep   best improvement on sqrt metrics: nodes ranked along a Hilbert
+//                                  curve, whole 64 x 64 blocks of pairs decided by the box form of the new-edge bound.
+//   two_opt_first.hpp  k_first     first improvement: small fixed grid, moves carried out of place by the next launch.
+//   two_opt_step.hpp               what they share: arguments, in-launch hand-off, MoveView, apply_step.
+// The two selection rules:
 //   FIRST  = alg_2opt       (src/heuristics.c:438-502): first improving pair after the cursor in
 //            (i<j) order, applied at once, scan resumes right after it; stop after a sweep that
 //            did not lower obj_best (:492).
