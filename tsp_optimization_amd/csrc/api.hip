@@ -113,6 +113,8 @@ __global__ __launch_bounds__(256) void k_perm_cost(const double2 *__restrict__ c
 }
 }  // namespace
 
+using tsp::DevBuf;
+
 extern "C" {
 
 const char *tsp_dev_last_error(void) { return tsp::g_last_error; }
@@ -165,6 +167,7 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
     tsp_dev_inst *inst = new tsp_dev_inst();
     inst->ctx = ctx;
     inst->n = n;
+    struct Guard { tsp_dev_inst *i; ~Guard() { if (i) tsp_dev_inst_destroy(i); } } guard{inst};   // an early error return frees what exists
     // unknown types (the reference's parser leaves -1) use EUC_2D: src/distutil.c:90-91
     inst->wtype = (weight_type >= 0 && weight_type <= 5) ? weight_type : TSP_EUC_2D;
     inst->integer_cost = integer_cost ? 1 : 0;
@@ -249,6 +252,7 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
         TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));   // the staging vectors die with this scope
     }
     TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    guard.i = nullptr;
     *out = inst;
     return TSP_OK;
 }
@@ -272,11 +276,11 @@ int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count
         if (i[k] < 0 || i[k] >= inst->n || j[k] < 0 || j[k] >= inst->n) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    int *d_i = nullptr, *d_j = nullptr;
-    double *d_o = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_i, sizeof(int) * (size_t)count));
-    TSP_HIP_TRY(hipMalloc(&d_j, sizeof(int) * (size_t)count));
-    TSP_HIP_TRY(hipMalloc(&d_o, sizeof(double) * (size_t)count));
+    DevBuf<int> d_i, d_j;
+    DevBuf<double> d_o;
+    TSP_HIP_TRY(d_i.alloc((size_t)count));
+    TSP_HIP_TRY(d_j.alloc((size_t)count));
+    TSP_HIP_TRY(d_o.alloc((size_t)count));
     TSP_HIP_TRY(hipMemcpyAsync(d_i, i, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     TSP_HIP_TRY(hipMemcpyAsync(d_j, j, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
@@ -286,22 +290,20 @@ int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count
     TSP_HIP_TRY(hipMemcpyAsync(out, d_o, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
-    (void)hipFree(d_i); (void)hipFree(d_j); (void)hipFree(d_o);
     return TSP_OK;
 }
 
 int tsp_dev_selftest_raw_sqrt(tsp_dev_ctx *ctx, const double *in, int count, double *out) {
     if (!ctx || !in || !out || count < 1) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(ctx->device));
-    double *d_in = nullptr, *d_out = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_in, sizeof(double) * (size_t)count));
-    TSP_HIP_TRY(hipMalloc(&d_out, sizeof(double) * (size_t)count));
+    DevBuf<double> d_in, d_out;
+    TSP_HIP_TRY(d_in.alloc((size_t)count));
+    TSP_HIP_TRY(d_out.alloc((size_t)count));
     TSP_HIP_TRY(hipMemcpyAsync(d_in, in, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_raw_sqrt, dim3((count + 255) / 256), dim3(256), 0, ctx->stream, d_in, count, d_out);
     TSP_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(ctx->stream));
     TSP_HIP_TRY(hipGetLastError());
-    (void)hipFree(d_in); (void)hipFree(d_out);
     return TSP_OK;
 }
 
@@ -315,11 +317,11 @@ int tsp_dev_perm_cost(tsp_dev_inst *inst, int B, const int *perm, int64_t perm_s
         }
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    int *d_p = nullptr;
-    double *d_c = nullptr;
+    DevBuf<int> d_p;
+    DevBuf<double> d_c;
     const size_t words = (size_t)(B - 1) * perm_stride + n;
-    TSP_HIP_TRY(hipMalloc(&d_p, sizeof(int) * words));
-    TSP_HIP_TRY(hipMalloc(&d_c, sizeof(double) * (size_t)B));
+    TSP_HIP_TRY(d_p.alloc(words));
+    TSP_HIP_TRY(d_c.alloc((size_t)B));
     TSP_HIP_TRY(hipMemcpyAsync(d_p, perm, sizeof(int) * words, hipMemcpyHostToDevice, s));
     TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
         hipLaunchKernelGGL((k_perm_cost<WTC, INTC>), dim3(B), dim3(256), 0, s, inst->d_coord, d_p,
@@ -328,7 +330,6 @@ int tsp_dev_perm_cost(tsp_dev_inst *inst, int B, const int *perm, int64_t perm_s
     TSP_HIP_TRY(hipMemcpyAsync(cost, d_c, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
-    (void)hipFree(d_p); (void)hipFree(d_c);
     return TSP_OK;
 }
 

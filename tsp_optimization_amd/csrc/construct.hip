@@ -639,23 +639,22 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
     const int n = inst->n;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    int *d_starts = nullptr, *d_succ = nullptr, *d_status = nullptr;
-    double *d_urand = nullptr, *d_obj = nullptr;
-    unsigned char *d_vis = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_starts, sizeof(int) * (size_t)B));
-    TSP_HIP_TRY(hipMalloc(&d_status, sizeof(int) * (size_t)B));
-    TSP_HIP_TRY(hipMalloc(&d_obj, sizeof(double) * (size_t)B));
-    TSP_HIP_TRY(hipMalloc(&d_succ, sizeof(int) * (size_t)B * n));
-    TSP_HIP_TRY(hipMalloc(&d_vis, (size_t)B * n));
+    DevBuf<int> d_starts, d_succ, d_status, d_slots;
+    DevBuf<double> d_urand, d_obj;
+    DevBuf<unsigned char> d_vis;
+    TSP_HIP_TRY(d_starts.alloc((size_t)B));
+    TSP_HIP_TRY(d_status.alloc((size_t)B));
+    TSP_HIP_TRY(d_obj.alloc((size_t)B));
+    TSP_HIP_TRY(d_succ.alloc((size_t)B * n));
+    TSP_HIP_TRY(d_vis.alloc((size_t)B * n));
     TSP_HIP_TRY(hipMemcpyAsync(d_starts, starts, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
     TSP_HIP_TRY(hipMemsetAsync(d_succ, 0, sizeof(int) * (size_t)B * n, s));  // CALLOC'd edges, solver.c:270
     if (kind == TSP_CONSTRUCT_GRASP) {
-        TSP_HIP_TRY(hipMalloc(&d_urand, sizeof(double) * (size_t)B * n));
+        TSP_HIP_TRY(d_urand.alloc((size_t)B * n));
         TSP_HIP_TRY(hipMemcpyAsync(d_urand, urand, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, s));
     }
     // greedy on a sqrt metric with the Hilbert groups at hand: the spatial kernel, one wave per start
     bool use_nn = false;
-    int *d_slots = nullptr;
     {
         const char *off = getenv("TSP_CONSTRUCT_NN");
         const bool icoord = inst->wtype == tsp::WT_EUC_2D_ICOORD || inst->wtype == tsp::WT_CEIL_2D_ICOORD || inst->wtype == tsp::WT_ATT_ICOORD;
@@ -671,7 +670,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         if (use_nn) {
             std::vector<int> slots((size_t)B, 0);
             for (int b = 0; b < B; ++b) if (starts[b] >= 0 && starts[b] < n) slots[b] = inst->h_sinv[starts[b]];
-            TSP_HIP_TRY(hipMalloc(&d_slots, sizeof(int) * (size_t)B));
+            TSP_HIP_TRY(d_slots.alloc((size_t)B));
             TSP_HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
             TSP_HIP_TRY(hipStreamSynchronize(s));   // `slots` dies with this scope
             hipError_t e_nn = hipSuccess;
@@ -742,8 +741,6 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         int *sp = succ + (size_t)b * tour_stride;
         for (int v = 0; v < n; ++v) sp[(size_t)v * succ_stride] = h_succ[(size_t)b * n + v];
     }
-    (void)hipFree(d_starts); (void)hipFree(d_status); (void)hipFree(d_obj); (void)hipFree(d_succ);
-    (void)hipFree(d_vis); (void)hipFree(d_urand); (void)hipFree(d_slots);
     return (B == 1) ? worst : TSP_OK;
 }
 
@@ -754,8 +751,9 @@ int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float 
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
     const size_t bytes = (size_t)n * n * (as_int32 ? 4 : 8);
-    void *d_out = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_out, bytes));
+    DevBuf<char> d_out_buf;
+    TSP_HIP_TRY(d_out_buf.alloc(bytes));
+    void *d_out = d_out_buf.p;
     hipEvent_t e0, e1;
     TSP_HIP_TRY(hipEventCreate(&e0));
     TSP_HIP_TRY(hipEventCreate(&e1));
@@ -784,7 +782,6 @@ int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float 
         TSP_HIP_TRY(hipStreamSynchronize(s));
     }
     TSP_HIP_TRY(hipGetLastError());
-    (void)hipFree(d_out);
     if (kernel_ms) *kernel_ms = ms;
     return TSP_OK;
 }

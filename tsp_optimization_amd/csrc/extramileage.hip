@@ -172,16 +172,16 @@ extern "C" int tsp_dev_extramileage(tsp_dev_inst *inst, int *succ, int succ_stri
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
     const int gx = (n + kScanThreads - 1) / kScanThreads, gy = (n + kXmRows - 1) / kXmRows;
-    Partial *d_part = nullptr;
-    XmSlot *d_slots = nullptr;
-    unsigned char *d_vis = nullptr;
-    int *d_succ = nullptr;
-    XmState *d_st = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_part, sizeof(Partial) * (size_t)gx * gy));
-    TSP_HIP_TRY(hipMalloc(&d_slots, sizeof(XmSlot) * (size_t)(n + 1)));
-    TSP_HIP_TRY(hipMalloc(&d_vis, (size_t)n));
-    TSP_HIP_TRY(hipMalloc(&d_succ, sizeof(int) * (size_t)n));
-    TSP_HIP_TRY(hipMalloc(&d_st, sizeof(XmState)));
+    DevBuf<Partial> d_part;
+    DevBuf<XmSlot> d_slots;
+    DevBuf<unsigned char> d_vis;
+    DevBuf<int> d_succ;
+    DevBuf<XmState> d_st;
+    TSP_HIP_TRY(d_part.alloc((size_t)gx * gy));
+    TSP_HIP_TRY(d_slots.alloc((size_t)(n + 1)));
+    TSP_HIP_TRY(d_vis.alloc((size_t)n));
+    TSP_HIP_TRY(d_succ.alloc((size_t)n));
+    TSP_HIP_TRY(d_st.alloc(1));
     TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
         hipLaunchKernelGGL((k_xm_far<WTC, INTC>), dim3(gx, gy), dim3(kScanThreads), 0, s, inst->d_coord, n, d_part);
         hipLaunchKernelGGL((k_xm_init<WTC, INTC>), dim3(1), dim3(kApplyThreads), 0, s, inst->d_coord, n, d_part, gx * gy,
@@ -201,6 +201,5 @@ extern "C" int tsp_dev_extramileage(tsp_dev_inst *inst, int *succ, int succ_stri
     TSP_HIP_TRY(hipGetLastError());
     for (int v = 0; v < n; ++v) succ[(size_t)v * succ_stride] = h_succ[v];
     *obj = h_st.obj;
-    (void)hipFree(d_part); (void)hipFree(d_slots); (void)hipFree(d_vis); (void)hipFree(d_succ); (void)hipFree(d_st);
     return TSP_OK;
 }

@@ -135,6 +135,18 @@ struct tsp_dev_tours {
 // ---- error plumbing ------------------------------------------------------------------------
 namespace tsp {
 void set_last_error(const char *what, hipError_t e, const char *file, int line);
+
+// Call-local device scratch: released when the scope ends, so an early error return leaks nothing.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * count); }
+    operator T *() const { return p; }
+};
 }
 #define TSP_HIP_TRY(expr)                                                    \
     do {                                                                     \

@@ -292,6 +292,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     tsp_dev_tours *t = new tsp_dev_tours();
     t->inst = inst; t->B = B; t->n = inst->n;
+    struct Guard { tsp_dev_tours *t; ~Guard() { if (t) tsp_dev_tours_destroy(t); } } guard{t};   // an early error return frees what exists
     // FIRST-mode chunk geometry.  A step costs a launch (~10 us of latency) plus the evaluation of
     // rows x n pairs per tour; only the pairs up to the first improving one are useful.  One tour:
     // latency dominates, 32 rows is the measured optimum at n = 10000.  Many tours: keep the smallest
@@ -379,6 +380,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipMalloc(&t->d_row_evals, (size_t)B * t->max_tile_rows * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_row_slot, (size_t)B * t->max_tile_rows * sizeof(Partial)));
     TSP_HIP_TRY(hipHostMalloc(&t->h_state, (size_t)B * sizeof(TourState)));
+    guard.t = nullptr;
     *out = t;
     return TSP_OK;
 }
