@@ -1,6 +1,6 @@
 """GPU parity of the sorted best-improvement sweep (k_move_recs + k_sweep, two_opt_sweep.hpp).
 
-By default the engine uses it for n >= 4096, where the CPU oracle needs minutes per descent; these tests set
+By default the engine uses it for n >= 1000, where the CPU oracle soon needs minutes per descent; these tests set
 TSP_SORTED_MIN_N=0 so that the same kernels run on the small instances the oracle finishes in seconds, and check
 tours, costs and counters against alg_2opt_tabu's restatement (tabusearch.c:107-178).  At full size the sorted
 and the tiled sweep are run against each other (they must agree move for move)."""

@@ -7,7 +7,7 @@ from tsp_optimization_amd import engine as E
 from helpers import rand_instance
 from oracle import oracle as O
 ctx = E.Context(0)
-for n in (500, 1000, 1500, 2000, 3000, 4000, 6000, 20000, 50000):
+for n in [int(x) for x in os.environ.get('NS', '500,1000,1500,2000,3000,4000,6000,20000,50000').split(',')]:
     xy = rand_instance(n)
     row = []
     for min_n in ("0", "1000000000"):

@@ -329,12 +329,15 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     const dim3 gb = scan_grid<TSP_2OPT_BEST>(t), gf = scan_grid<TSP_2OPT_FIRST>(t);
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
     t->partial_per_tour = std::max(t->partial_per_tour, (size_t)((inst->n + kScanThreads - 1) / kScanThreads) * t->first_grid_rows);
-    t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 4096);
+    t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 1000);
     size_t rec_per_tour = (size_t)inst->n;
     size_t cl_words = (size_t)B * 64 * 64;   // k_first: one arrival counter per tour x tile row, 64 ints apart
     if (inst->d_sperm) {
-        // k_sweep blocks per tour: whole clusters, about two waves per SIMD on the chip for one tour
-        const int want = env_int("TSP_SWEEP_BLOCKS", std::min(768, std::max(16, 768 / B)));
+        // k_sweep blocks per tour: whole clusters; about eight group pairs per block, between one and three blocks
+        // per CU for one tour (measured over n = 500 .. 15 000: 256 blocks are best below ~4000 nodes, 512-768 above)
+        const long long gp = (long long)inst->ng * (inst->ng + 1) / 2;
+        const int one_tour = (int)std::min<long long>(768, std::max<long long>(256, gp / 8));
+        const int want = env_int("TSP_SWEEP_BLOCKS", std::max(16, one_tour / B));
         t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
         rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
