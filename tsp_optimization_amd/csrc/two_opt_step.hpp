@@ -186,6 +186,7 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
 #ifdef TSP_STAMPS
                                            , unsigned long long *stamps
 #endif
+                                           , double *chunk_buf = nullptr   // FLAT: 4096 doubles of LDS the caller no longer needs
 ) {
     constexpr int TJ = kScanThreads * RJ;
     const int n = a.n, rpb = a.rows_per_block;
@@ -305,8 +306,10 @@ __device__ __forceinline__ void apply_step(const StepArgs &a, int tour, int row_
     double final_cost = 0.0;
     if constexpr (MODE == TSP_2OPT_BEST) {
         if (!found) {
-            __shared__ double s_chunk[(INT || WT == WT_CEIL_2D) ? 1 : 4096];
-            final_cost = tour_cost_block<WT, INT>(a.coord, order, pos, n, s_d, s_chunk);
+            // the sequential cost of non-integer lengths is staged through 32 KB of LDS: the sweep lends its staging
+            // area (its own 32 KB would cost the float-cost variants two thirds of their resident blocks)
+            __shared__ double s_chunk[(INT || WT == WT_CEIL_2D || FLAT) ? 1 : 4096];
+            final_cost = tour_cost_block<WT, INT>(a.coord, order, pos, n, s_d, FLAT ? chunk_buf : s_chunk);
         }
     }
 
