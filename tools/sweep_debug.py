@@ -3,6 +3,8 @@ import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np
+from tsp_optimization_amd import build as BLD
+if os.environ.get('LIBDIR'): BLD.LIB_DIR = os.path.join(R, 'tsp_optimization_amd', os.environ['LIBDIR'])
 from tsp_optimization_amd import engine as E
 from helpers import load_instance
 ctx = E.Context(0)

@@ -277,15 +277,12 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
                             (rj.id != ri[u].succ) & (rj.succ != ri[u].id);
                     any2 = any2 | ok[u];
                 }
-                if (any2) {   // tier 2: the exact delta (rare: one copy of the code, the row read again from LDS)
-                    const unsigned rows4 = (unsigned)idx[0] | ((unsigned)idx[1] << 8) | ((unsigned)idx[2] << 16) | ((unsigned)idx[3] << 24);
-                    unsigned okm = (ok[0] ? 1u : 0u) | (ok[1] ? 2u : 0u) | (ok[2] ? 4u : 0u) | (ok[3] ? 8u : 0u);
-#pragma unroll 1
-                    for (int u = 0; u < 4; ++u, okm >>= 1) {
-                        if (okm & 1u) {
-                            const NodeRec r2 = rows[(rows4 >> (8 * u)) & 0xffu];
-                            const double delta = pair_delta<WT, INT>(r2, rj);
-                            const u64 kk = make_key(min(r2.id, rj.id), max(r2.id, rj.id));
+                if (any2) {   // tier 2: the exact delta
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (ok[u]) {
+                            const double delta = pair_delta<WT, INT>(ri[u], rj);
+                            const u64 kk = make_key(min(ri[u].id, rj.id), max(ri[u].id, rj.id));
                             if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) { bd = delta; key = kk; bound = bd; }
                         }
                     }
