@@ -247,3 +247,44 @@ def test_greedy_large_instance_kernel_matches_the_oracle(eng, ctx, ic):
     for b, s0 in enumerate((123, 16999)):
         _, es, eo = O.greedy(xy, O.EUC_2D, start=s0, integer_cost=ic)
         assert (succ[b] == es).all() and obj[b] == eo
+
+
+def _edge_cases():
+    rng = np.random.default_rng(9)
+    cases = []
+    for n in (4, 5, 6, 64, 128, 512):
+        cases.append(("identical-%d" % n, np.full((n, 2), 7.0), O.EUC_2D, 1))
+        cases.append(("collinear-%d" % n, np.stack([np.arange(n) * 3.0, np.zeros(n)], 1), O.EUC_2D, 1))
+    cases.append(("huge-coordinates", rng.integers(10**9, 10**9 + 5 * 10**6, size=(300, 2)).astype(np.float64), O.EUC_2D, 1))
+    cases.append(("span-above-the-integer-variant-bound", rng.integers(0, 3 * 10**6, size=(300, 2)).astype(np.float64), O.EUC_2D, 1))
+    cases.append(("negative-non-integer", rng.uniform(-1e4, 1e4, size=(257, 2)), O.ATT, 1))
+    cases.append(("two-far-clusters", np.vstack([rng.integers(0, 50, (100, 2)), rng.integers(10**6, 10**6 + 50, (100, 2))]).astype(np.float64), O.CEIL_2D, 1))
+    cases.append(("fcost-collinear", np.stack([np.arange(130) * 0.5, np.arange(130) * 0.25], 1), O.EUC_2D, 0))
+    return cases
+
+
+@pytest.mark.parametrize("case", _edge_cases(), ids=lambda c: c[0])
+def test_edge_inputs_all_kernels(eng, ctx, sorted_always, case):
+    """Tiny n, identical and collinear points (every distance tied or zero), huge / negative / non-integer
+    coordinates, sizes on the group and tile boundaries: construction, both rules (sorted sweep forced), both engines."""
+    name, xy, wt, ic = case
+    n = len(xy)
+    rng = np.random.default_rng(n)
+    inst = eng.Instance(ctx, xy, wt, ic)
+    for s0 in (0, n - 1):
+        succ, obj, _ = inst.construct(eng.GREEDY, np.array([s0], dtype=np.int32))
+        _, es, eo = O.greedy(xy, wt, start=s0, integer_cost=ic)
+        assert (succ[0] == es).all() and obj[0] == eo
+    tour = random_tour(n, rng)
+    cost = O.succ_cost(xy, wt, tour, integer_cost=ic)
+    _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
+    for engine in ((1, 2) if n >= 8 else (1,)):
+        rc, s, o, st = inst.two_opt(tour, cost, mode=eng.FIRST, engine=engine)
+        assert (s == fs).all() and o == fo
+        assert (st["sweeps"], st["evals"], st["moves"]) == (fst["sweeps"], fst["evals"], fst["moves"])
+    if n <= 300:
+        rc, s, o, st = inst.two_opt(tour, cost, mode=eng.BEST, engine=1)
+        _, bs, bo, bst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic)
+        assert (s == bs).all() and o == bo
+        assert (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+    inst.close()
