@@ -297,13 +297,21 @@ def main():
                       "cannot be built here (needs cplex.h)" % (sweeps, cst["evals"], cst["seconds"]),
         }
 
-    if rank == 0:
-        print(json.dumps(out))
     tours.close()
     inst.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would otherwise be
+        # flushed at exit, after this line: push it out first so that the JSON line is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

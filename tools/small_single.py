@@ -6,7 +6,7 @@ import numpy as np
 from tsp_optimization_amd import engine as E
 from helpers import load_instance
 ctx = E.Context(0)
-for name in ("berlin52", "pr299", "att532", "pr1002", "rand2000", "rand5000"):
+for name in os.environ.get("NAMES", "berlin52,pr299,att532,pr1002,rand2000,rand5000").split(","):
     xy, wt = load_instance(name)
     inst = E.Instance(ctx, xy, wt, 1)
     succ, obj, _ = inst.construct(E.GREEDY, np.array([0], dtype=np.int32))
