@@ -113,6 +113,7 @@ struct tsp_dev_tours {
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;
     std::vector<double> h_obj0;
+    std::vector<int> h_order_buf;    // staging of tsp_dev_tours_upload
     // pinned host mirror of the states, for polling
     tsp::TourState *h_state = nullptr;
     // scan geometry

@@ -427,7 +427,8 @@ int tsp_dev_tours_upload(tsp_dev_tours *t, const int *succ, int succ_stride, int
     if (!t || !succ || succ_stride < 1) return TSP_DEV_E_ARG;
     const int n = t->n, B = t->B;
     hipStream_t s = t->inst->ctx->stream;
-    std::vector<int> order((size_t)B * n);
+    std::vector<int> &order = t->h_order_buf;   // lives until the reset below has synchronised
+    order.resize((size_t)B * n);
     std::vector<char> seen((size_t)n);
     for (int b = 0; b < B; ++b) {
         const int *sp = succ + (size_t)b * tour_stride;
@@ -444,8 +445,7 @@ int tsp_dev_tours_upload(tsp_dev_tours *t, const int *succ, int succ_stride, int
     t->h_obj0.assign((size_t)B, 0.0);
     if (obj) for (int b = 0; b < B; ++b) t->h_obj0[b] = obj[b];
     TSP_HIP_TRY(hipMemcpyAsync(t->d_order0, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
-    return tsp_dev_tours_reset(t);
+    return tsp_dev_tours_reset(t);   // one synchronisation for the upload and the reset
 }
 
 int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t tour_stride, double *obj,
