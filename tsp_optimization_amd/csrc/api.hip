@@ -347,6 +347,9 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         const char *force = getenv("TSP_ENGINE");
         const bool lds_ok = tsp_lds_fits(inst);
         bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
+        // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
+        // (tools/small_single.py: 15-35 % faster up to pr299, slower from att532 on and on GEO)
+        if (lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299) lds = true;
         if (force && *force == '1') lds = false;
         if (force && *force == '2' && lds_ok) lds = true;
         engine = lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID;
