@@ -21,6 +21,9 @@ for c in range(cases):
     if rng.random() < 0.5: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
     else: xy = rng.uniform(-5000, 5000, size=(n, 2))
     if wt == O.CEIL_2D: ic = 1
+    # float costs on MAN_2D / MAX_2D (dy = |y2 - y2| = 0 in the reference) can cycle forever on rounding noise: the
+    # reference relies on its time limit there, and so would this run
+    if wt in (O.MAN_2D, O.MAX_2D): ic = 1
     inst = E.Instance(ctx, xy, wt, ic)
     s0 = int(rng.integers(0, n))
     succ, obj, _ = inst.construct(E.GREEDY, np.array([s0], dtype=np.int32))
