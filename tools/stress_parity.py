@@ -14,12 +14,18 @@ rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
 sizes = [4, 5, 6, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640]   # the CPU oracle bounds the run time
 cases = int(os.environ.get("CASES", "60"))
 bad = 0
+import time
 for c in range(cases):
+    t_case = time.perf_counter()
     n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(4, 600))
     wt = int(rng.choice([O.EUC_2D, O.ATT, O.CEIL_2D, O.MAN_2D, O.MAX_2D]))
     ic = int(rng.random() < 0.75)
-    if rng.random() < 0.5: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
+    int_coords = rng.random() < 0.5
+    if int_coords: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
     else: xy = rng.uniform(-5000, 5000, size=(n, 2))
+    # float costs with exactly tied distances (coincident or lattice points) can make the reference's best-improvement
+    # loop cycle forever on rounding-noise deltas (seen: ATT, 127 points on a 20 x 20 lattice): integer costs there
+    if int_coords: ic = 1
     if wt == O.CEIL_2D: ic = 1
     # float costs on MAN_2D / MAX_2D (dy = |y2 - y2| = 0 in the reference) can cycle forever on rounding noise: the
     # reference relies on its time limit there, and so would this run
@@ -39,7 +45,7 @@ for c in range(cases):
     _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
     ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
     inst.close()
-    print("case %d n %d wt %d ic %d %s" % (c, n, wt, ic, "ok" if ok else "MISMATCH"), flush=True)
+    print("case %d n %d wt %d ic %d %s  %.2f s" % (c, n, wt, ic, "ok" if ok else "MISMATCH", time.perf_counter() - t_case), flush=True)
     if not ok:
         bad += 1
         print("MISMATCH case %d: n %d wt %d ic %d" % (c, n, wt, ic))
