@@ -63,7 +63,8 @@ enum {
 /* 2-opt execution engine (a performance choice; results are identical) */
 enum {
     TSP_ENGINE_AUTO = 0,
-    TSP_ENGINE_GRID = 1, /* many workgroups per tour, tour state in HBM, one launch pair per step */
+    TSP_ENGINE_GRID = 1, /* many workgroups per tour, tour state in HBM, one launch (two for the sorted
+                            best-improvement sweep) per step */
     TSP_ENGINE_LDS = 2   /* one workgroup per tour, whole descent inside one launch, state in LDS */
 };
 
@@ -80,7 +81,7 @@ typedef struct {
     int64_t reversed;      /* tour positions rewritten by segment reversals                      */
     int64_t pairs_scanned; /* pairs the device actually evaluated (>= evals in FIRST mode: a
                               chunk is scanned past the first improving pair)                    */
-    int64_t steps;         /* scan+apply launch pairs (GRID) or chunk iterations (LDS)           */
+    int64_t steps;         /* steps: launches of a step kernel (GRID) or chunk iterations (LDS)   */
     double seconds;        /* wall time of the call, host clock                                  */
     double device_ms;      /* device time of the call, HIP events on the engine's stream         */
 } tsp_two_opt_stats;
@@ -165,14 +166,15 @@ int tsp_dev_tours_upload(tsp_dev_tours *t, const int *succ, int succ_stride, int
 int tsp_dev_tours_reset(tsp_dev_tours *t);
 int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t tour_stride,
                            double *obj, tsp_two_opt_stats *stats);
-/* Run at most max_steps GRID-engine steps (one step = one scan launch + one apply launch per
- * tour batch) in `mode`; max_steps < 0 = until every tour is at its local optimum.
+/* Run at most max_steps GRID-engine steps (one step = one scan of the selection rule's range and at
+ * most one move per tour) in `mode`; max_steps < 0 = until every tour is at its local optimum.
  * Does not wait for completion unless `sync` != 0.  *all_done (if not NULL, sync only). */
 int tsp_dev_tours_run(tsp_dev_tours *t, int mode, int64_t max_steps, double time_limit_s, int sync,
                       int *all_done);
-/* Launch the scan kernel alone `reps` times on the current tours (BEST mode, full sweep) with
- * HIP events around each launch on the engine's stream; returns the mean launch duration in
- * *mean_ms and the pairs evaluated per launch in *evals_per_launch.  Roofline measurement. */
+/* Launch `reps` best-improvement steps back to back on the current tours (they continue the descent)
+ * with HIP events around the run on the engine's stream; returns the mean duration of a step's
+ * launches in *mean_ms and the reference-equivalent evaluations per step in *evals_per_launch.
+ * Roofline measurement. */
 int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t *evals_per_launch);
 /* min over tours of (cost, tour index) packed as (int64(cost) << 24 | index); the value the
  * multi-start all-reduce(min) combines across ranks.  true_cost != 0 recomputes the cost from
