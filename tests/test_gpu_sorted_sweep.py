@@ -288,3 +288,25 @@ def test_edge_inputs_all_kernels(eng, ctx, sorted_always, case):
         assert (s == bs).all() and o == bo
         assert (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
     inst.close()
+
+
+@pytest.mark.parametrize("name", ["att532", "rand2000", "d493"])
+def test_grasp_spatial_and_dense_kernels_agree_with_the_oracle(eng, ctx, monkeypatch, name):
+    """grasp() (heuristics.c:82-156) through k_construct_nn (the runner-up is a second nearest-neighbour query among
+    the nodes with a smaller index than the winner) and through k_construct_lds, same URAND stream as the oracle."""
+    xy, wt = load_instance(name)
+    n = len(xy)
+    starts = np.array([5, n - 1], dtype=np.int32)
+    exp, urand = [], np.zeros((2, n))
+    for b, s0 in enumerate(starts):
+        O.srandom(100 + b)
+        urand[b] = [O.urand() for _ in range(n)]
+        O.srandom(100 + b)
+        exp.append(O.grasp(xy, wt, start=int(s0)))
+    for nn in ("1", "0"):
+        monkeypatch.setenv("TSP_CONSTRUCT_NN", nn)
+        inst = eng.Instance(ctx, xy, wt, 1)
+        succ, obj, _ = inst.construct(eng.GRASP, starts, urand)
+        inst.close()
+        for b in range(2):
+            assert (succ[b] == exp[b][1]).all() and obj[b] == exp[b][2], (nn, b)

@@ -266,12 +266,13 @@ __host__ __device__ inline size_t nn_lds_bytes(int n_slots, int ng) {
     return sizeof(CT) * (size_t)n_slots + sizeof(int) * (size_t)n_slots + (sizeof(unsigned long long) + sizeof(double4)) * (size_t)ng + 64;
 }
 
-template <int WT, bool INT, typename CT, bool PACK>
+template <int WT, bool INT, typename CT, bool PACK, bool IS_GRASP>
 __global__ __launch_bounds__(64) void k_construct_nn(const double2 *__restrict__ coord, const int *__restrict__ sperm,
                                                      const double4 *__restrict__ gbox, int n, int ng, int n_slots,
                                                      double ox, double oy, const int *__restrict__ starts,
-                                                     const int *__restrict__ start_slots, int *__restrict__ succ_all,
-                                                     double *__restrict__ obj, int *__restrict__ status) {
+                                                     const int *__restrict__ start_slots, const double *__restrict__ urand,
+                                                     int *__restrict__ succ_all, double *__restrict__ obj,
+                                                     int *__restrict__ status) {
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
     // a distance is at least the root minus 1/2 when it is rounded to nearest (EUC_2D integer costs), at least the
     // root otherwise: a group whose box is farther than best + slack cannot hold a node as near as the best
@@ -328,80 +329,78 @@ __global__ __launch_bounds__(64) void k_construct_nn(const double2 *__restrict__
                 if (lb2[r] < near2) { near2 = lb2[r]; near_g = g; }
             }
         }
-        double bd = DBL_MAX;
-        int bid = 0x7fffffff, bslot = -1;
         if constexpr (PACK) {
-            // integer costs below 2^31, ids and slots below 2^15: (distance, id, slot) is one 64-bit key and a
-            // reduction one DPP min; a non-negative double orders like its bits
             const unsigned long long nb = wave_min_u64((unsigned long long)__double_as_longlong(near2));
-            const unsigned long long who = __ballot((unsigned long long)__double_as_longlong(near2) == nb);
-            near_g = __builtin_amdgcn_readlane(near_g, __builtin_ctzll(who));
-            unsigned long long best = ~0ull;
+            near_g = __builtin_amdgcn_readlane(near_g, __builtin_ctzll(__ballot((unsigned long long)__double_as_longlong(near2) == nb)));
+        } else {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o2 = __shfl_xor(near2, off);
+                const int og = __shfl_xor(near_g, off);
+                if (o2 < near2 || (o2 == near2 && og < near_g)) { near2 = o2; near_g = og; }
+            }
+        }
+        // One query: the nearest live node with id < id_limit, (distance, id) smallest first == the reference's scan
+        // with its strict '<'.  B: the nearest group's nodes; C: every other group that could hold a node as near
+        // (ties included: the lower id wins) -- every live group if B found nothing.
+        auto query = [&](int id_limit, double &qd, int &qid, int &qslot) -> bool {
+            double bd = DBL_MAX;
+            int bid = 0x7fffffff, bslot = -1;
+            unsigned long long best = ~0ull;   // PACK: (distance << 30 | id << 15 | slot), integer costs below 2^31
             auto eval_group = [&](int g) {
                 const int slot = g * 64 + lane;
-                const bool bit = (s_alive[g] >> lane) & 1ull;
-                const CT c = s_xy[slot];
                 const int id = s_id[slot];
+                const bool bit = ((s_alive[g] >> lane) & 1ull) && id < id_limit;
+                const CT c = s_xy[slot];
                 const double d = dist_xy<WT, INT>(curx, cury, (double)c.x, (double)c.y);
-                const unsigned long long k = ((unsigned long long)(long long)d << 30) | ((unsigned long long)id << 15) | (unsigned)slot;
-                if (bit && k < best) best = k;
+                if constexpr (PACK) {
+                    const unsigned long long k = ((unsigned long long)(long long)d << 30) | ((unsigned long long)id << 15) | (unsigned)slot;
+                    if (bit && k < best) best = k;
+                } else {
+                    if (bit && (d < bd || (d == bd && id < bid))) { bd = d; bid = id; bslot = slot; }
+                }
+            };
+            auto reduce_best = [&]() {
+                if constexpr (PACK) {
+                    best = wave_min_u64(best);
+                    bd = best == ~0ull ? DBL_MAX : (double)(best >> 30);
+                    bid = (int)((best >> 15) & 0x7fff); bslot = (int)(best & 0x7fff);
+                } else {
+                    const unsigned long long md = wave_min_u64((unsigned long long)__double_as_longlong(bd));
+                    const unsigned long long mi = wave_min_u64((unsigned long long)__double_as_longlong(bd) == md ? (unsigned long long)(unsigned)bid : ~0ull);
+                    const int src = __builtin_ctzll(__ballot((unsigned long long)__double_as_longlong(bd) == md && (unsigned long long)(unsigned)bid == mi));
+                    bd = __longlong_as_double((long long)md); bid = (int)(unsigned)mi; bslot = __builtin_amdgcn_readlane(bslot, src);
+                }
             };
             eval_group(near_g);
-            const unsigned long long b1 = wave_min_u64(best);
-            const double reach = (double)(b1 >> 30) + kRound;
-            const double thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9;
+            reduce_best();
+            double thr2 = DBL_MAX;
+            if (bd < DBL_MAX) { const double reach = bd + kRound; thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9; }
 #pragma unroll
             for (int r = 0; r < kNnMaxRounds; ++r) {
                 const int g = lane + 64 * r;
-                unsigned long long cand = __ballot(g != near_g && lb2[r] <= thr2);
+                unsigned long long cand = __ballot(g != near_g && lb2[r] < DBL_MAX && lb2[r] <= thr2);
                 while (cand) {
                     const int bit = __builtin_ctzll(cand);
                     cand &= cand - 1;
                     eval_group(bit + 64 * r);
                 }
             }
-            const unsigned long long b2 = wave_min_u64(best);
-            bd = (double)(b2 >> 30); bid = (int)((b2 >> 15) & 0x7fff); bslot = (int)(b2 & 0x7fff);
-        } else {
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o2 = __shfl_xor(near2, off);
-            const int og = __shfl_xor(near_g, off);
-            if (o2 < near2 || (o2 == near2 && og < near_g)) { near2 = o2; near_g = og; }
-        }
-        // B: its nodes; (distance, node id) smallest first == the reference's scan with its strict '<'
-        auto eval_group = [&](int g) {
-            const int slot = g * 64 + lane;
-            const bool bit = (s_alive[g] >> lane) & 1ull;
-            const CT c = s_xy[slot];
-            const int id = s_id[slot];
-            const double d = dist_xy<WT, INT>(curx, cury, (double)c.x, (double)c.y);
-            if (bit && (d < bd || (d == bd && id < bid))) { bd = d; bid = id; bslot = slot; }
+            reduce_best();
+            qd = bd; qid = bid; qslot = bslot;
+            return bd < DBL_MAX;
         };
-        auto reduce_best = [&]() {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double od = __shfl_xor(bd, off);
-                const int oi = __shfl_xor(bid, off), os = __shfl_xor(bslot, off);
-                if (od < bd || (od == bd && oi < bid)) { bd = od; bid = oi; bslot = os; }
+        double bd;
+        int bid, bslot;
+        (void)query(0x7fffffff, bd, bid, bslot);   // a live node exists: step < n
+        if constexpr (IS_GRASP) {
+            // grasp(), heuristics.c:117-131: with probability 0.1 the "previous running minimum" of the scan, i.e.
+            // the nearest node among those with a smaller index than the winner, if there is one
+            const double draw = urand[(size_t)b * n + (step - 1)];
+            if (!(draw < kGraspPickBest)) {
+                double rd; int rid, rslot;
+                if (query(bid, rd, rid, rslot)) { bd = rd; bid = rid; bslot = rslot; }
             }
-        };
-        eval_group(near_g);
-        reduce_best();
-        // C: every other group that could hold a node as near (ties included: the lower id wins)
-        const double reach = bd + kRound;
-        const double thr2 = (ATT10 ? 10.0 : 1.0) * reach * reach * (1.0 + 1e-9) + 1e-9;
-#pragma unroll
-        for (int r = 0; r < kNnMaxRounds; ++r) {
-            const int g = lane + 64 * r;
-            unsigned long long cand = __ballot(g != near_g && lb2[r] <= thr2);
-            while (cand) {
-                const int bit = __builtin_ctzll(cand);
-                cand &= cand - 1;
-                eval_group(bit + 64 * r);
-            }
-        }
-        reduce_best();
         }
         // the edge, and the node leaves the candidate set
         if (lane == 0) {
@@ -417,7 +416,8 @@ __global__ __launch_bounds__(64) void k_construct_nn(const double2 *__restrict__
     }
     if (lane == 0) {
         succ[cur_id] = start;                                   // heuristics.c:60-61
-        total += dist_xy<WT, INT>(curx, cury, sx, sy);          // :74
+        if constexpr (IS_GRASP) total += dist_xy<WT, INT>(curx, cury, sx, sy);   // :135, counted twice by grasp()
+        total += dist_xy<WT, INT>(curx, cury, sx, sy);          // :74 / :152
         obj[b] = total; status[b] = TSP_OK;
     }
 }
@@ -663,7 +663,8 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         // larger instances: coordinates stay in HBM/L2, LDS holds the alive masks and float boxes (k_construct_nn_big)
         const size_t need_big = (sizeof(float4) + sizeof(unsigned long long)) * (size_t)inst->ng + 64;
         const bool big = !small && inst->ng <= 4096 && need_big <= (size_t)158 * 1024;
-        use_nn = kind == TSP_CONSTRUCT_GREEDY && inst->d_sperm && !(off && *off == '0') && (small || big);
+        // greedy: both kernels; grasp (its runner-up is one more query with an id limit): the LDS-resident one
+        use_nn = inst->d_sperm && !(off && *off == '0') && (small || (big && kind == TSP_CONSTRUCT_GREEDY));
         // one 64-bit key per candidate when the costs are integers and ids/slots fit their fields
         const bool pack = inst->integer_cost && (small ? (inst->n_slots <= 32768 && inst->cost_bound < 2147483647.0)
                                                        : (inst->n_slots <= 262144 && inst->cost_bound < 268435455.0));
@@ -680,10 +681,12 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
                     using CT = std::conditional_t<IC, float2, double2>;
                     const double ox = IC ? inst->org_x : 0.0, oy = IC ? inst->org_y : 0.0;
                     if (small) {
-                        auto kf = pack ? k_construct_nn<WTC, INTC, CT, true> : k_construct_nn<WTC, INTC, CT, false>;
+                        const bool grasp = kind == TSP_CONSTRUCT_GRASP;
+                        auto kf = grasp ? (pack ? k_construct_nn<WTC, INTC, CT, true, true> : k_construct_nn<WTC, INTC, CT, false, true>)
+                                        : (pack ? k_construct_nn<WTC, INTC, CT, true, false> : k_construct_nn<WTC, INTC, CT, false, false>);
                         e_nn = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
                         hipLaunchKernelGGL(kf, dim3(B), dim3(64), need, s, inst->d_coord, inst->d_sperm, inst->d_gbox, n, inst->ng,
-                                           inst->n_slots, ox, oy, d_starts, d_slots, d_succ, d_obj, d_status);
+                                           inst->n_slots, ox, oy, d_starts, d_slots, (const double *)d_urand.p, d_succ, d_obj, d_status);
                     } else {
                         if (!inst->d_sxy) {   // rank-ordered coordinates, once per instance
                             e_nn = hipMalloc(&inst->d_sxy, sizeof(CT) * (size_t)inst->n_slots);
