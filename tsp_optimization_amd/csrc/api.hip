@@ -29,10 +29,15 @@ tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc
         if (!inst->scratch1) { *rc = tsp_dev_tours_create(inst, 1, &inst->scratch1); if (*rc) return nullptr; }
         return inst->scratch1;
     }
-    tsp_dev_tours *t = nullptr;
-    *rc = tsp_dev_tours_create(inst, B, &t);
-    *owned = true;
-    return t;
+    // batches: the handle of the last batch size is kept too (multi-start loops call with the same B again and
+    // again; creating a handle is ~20 allocations and, for the sorted sweep, a host-built table)
+    if (inst->scratch_b && inst->scratch_b_count != B) { tsp_dev_tours_destroy(inst->scratch_b); inst->scratch_b = nullptr; }
+    if (!inst->scratch_b) {
+        *rc = tsp_dev_tours_create(inst, B, &inst->scratch_b);
+        if (*rc) { inst->scratch_b = nullptr; return nullptr; }
+        inst->scratch_b_count = B;
+    }
+    return inst->scratch_b;
 }
 
 namespace {
@@ -262,6 +267,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     (void)hipSetDevice(inst->ctx->device);
     (void)hipStreamSynchronize(inst->ctx->stream);
     if (inst->scratch1) tsp_dev_tours_destroy(inst->scratch1);
+    if (inst->scratch_b) tsp_dev_tours_destroy(inst->scratch_b);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
     (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy);
     delete inst;

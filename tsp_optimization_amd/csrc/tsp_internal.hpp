@@ -59,6 +59,8 @@ struct tsp_dev_inst {
     int wtype = 0;        // kernel variant: unknown -> EUC_2D; *_ICOORD when the coordinates allow it
     int wtype_public = 0; // the caller's weight type
     tsp_dev_tours *scratch1 = nullptr;  // reusable single-tour handle of the host-tour entry points (B == 1)
+    tsp_dev_tours *scratch_b = nullptr; // ... and the handle of the last batch size used
+    int scratch_b_count = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // reusable timing events
     double filter_margin = 1e300; // root filter margin of the 2-opt scans (tsp_dist.hpp); 1e300 = off
     double prune_margin = 1e300;  // new-edge bound margin (tsp_dist.hpp); 1e300 = off
