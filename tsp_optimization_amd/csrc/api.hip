@@ -269,7 +269,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     if (inst->scratch1) tsp_dev_tours_destroy(inst->scratch1);
     if (inst->scratch_b) tsp_dev_tours_destroy(inst->scratch_b);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
-    (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy);
+    (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy); (void)hipFree(inst->cons_pool);
     delete inst;
 }
 

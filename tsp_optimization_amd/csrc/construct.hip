@@ -639,20 +639,30 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
     const int n = inst->n;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    DevBuf<int> d_starts, d_succ, d_status, d_slots;
-    DevBuf<double> d_urand, d_obj;
-    DevBuf<unsigned char> d_vis;
-    TSP_HIP_TRY(d_starts.alloc((size_t)B));
-    TSP_HIP_TRY(d_status.alloc((size_t)B));
-    TSP_HIP_TRY(d_obj.alloc((size_t)B));
-    TSP_HIP_TRY(d_succ.alloc((size_t)B * n));
-    TSP_HIP_TRY(d_vis.alloc((size_t)B * n));
-    TSP_HIP_TRY(hipMemcpyAsync(d_starts, starts, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
-    TSP_HIP_TRY(hipMemsetAsync(d_succ, 0, sizeof(int) * (size_t)B * n, s));  // CALLOC'd edges, solver.c:270
-    if (kind == TSP_CONSTRUCT_GRASP) {
-        TSP_HIP_TRY(d_urand.alloc((size_t)B * n));
-        TSP_HIP_TRY(hipMemcpyAsync(d_urand, urand, sizeof(double) * (size_t)B * n, hipMemcpyHostToDevice, s));
+    // scratch of a call, carved out of one per-instance allocation that only grows (multi-start loops call again
+    // and again with the same shape; seven hipMallocs cost more than a batch of small starts)
+    const bool grasp_call = kind == TSP_CONSTRUCT_GRASP;
+    const size_t bn = (size_t)B * n;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_urand = 0, o_obj = o_urand + up(grasp_call ? 8 * bn : 0), o_succ = o_obj + up(8 * (size_t)B),
+                 o_starts = o_succ + up(4 * bn), o_status = o_starts + up(4 * (size_t)B), o_slots = o_status + up(4 * (size_t)B),
+                 o_vis = o_slots + up(4 * (size_t)B), total_bytes = o_vis + up(bn);
+    if (inst->cons_pool_bytes < total_bytes) {
+        (void)hipFree(inst->cons_pool);
+        inst->cons_pool = nullptr; inst->cons_pool_bytes = 0;
+        TSP_HIP_TRY(hipMalloc(&inst->cons_pool, total_bytes));
+        inst->cons_pool_bytes = total_bytes;
     }
+    char *pool = static_cast<char *>(inst->cons_pool);
+    struct { double *p; } d_urand{grasp_call ? reinterpret_cast<double *>(pool + o_urand) : nullptr};
+    double *d_obj = reinterpret_cast<double *>(pool + o_obj);
+    int *d_succ = reinterpret_cast<int *>(pool + o_succ), *d_starts = reinterpret_cast<int *>(pool + o_starts),
+        *d_status = reinterpret_cast<int *>(pool + o_status), *d_slots = reinterpret_cast<int *>(pool + o_slots);
+    unsigned char *d_vis = reinterpret_cast<unsigned char *>(pool + o_vis);
+    TSP_HIP_TRY(hipMemcpyAsync(d_starts, starts, sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
+    TSP_HIP_TRY(hipMemsetAsync(d_succ, 0, sizeof(int) * bn, s));  // CALLOC'd edges, solver.c:270
+    if (grasp_call)
+        TSP_HIP_TRY(hipMemcpyAsync(d_urand.p, urand, sizeof(double) * bn, hipMemcpyHostToDevice, s));
     // greedy on a sqrt metric with the Hilbert groups at hand: the spatial kernel, one wave per start
     bool use_nn = false;
     {
@@ -671,7 +681,6 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         if (use_nn) {
             std::vector<int> slots((size_t)B, 0);
             for (int b = 0; b < B; ++b) if (starts[b] >= 0 && starts[b] < n) slots[b] = inst->h_sinv[starts[b]];
-            TSP_HIP_TRY(d_slots.alloc((size_t)B));
             TSP_HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, s));
             TSP_HIP_TRY(hipStreamSynchronize(s));   // `slots` dies with this scope
             hipError_t e_nn = hipSuccess;
@@ -715,7 +724,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
             if (kind == TSP_CONSTRUCT_GRASP) {
                 auto kf = k_construct_lds<WTC, INTC, true>;
                 attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                hipLaunchKernelGGL(kf, dim3(B), dim3(kConsLdsThreads), lds_bytes, s, inst->d_coord, n, d_starts, d_urand,
+                hipLaunchKernelGGL(kf, dim3(B), dim3(kConsLdsThreads), lds_bytes, s, inst->d_coord, n, d_starts, d_urand.p,
                                    d_succ, d_obj, d_status);
             } else {
                 auto kf = k_construct_lds<WTC, INTC, false>;
@@ -725,7 +734,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
             }
         } else if (kind == TSP_CONSTRUCT_GRASP)
             hipLaunchKernelGGL((k_construct<WTC, INTC, true>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
-                               d_starts, d_urand, d_vis, d_succ, d_obj, d_status);
+                               d_starts, d_urand.p, d_vis, d_succ, d_obj, d_status);
         else
             hipLaunchKernelGGL((k_construct<WTC, INTC, false>), dim3(B), dim3(kConsThreads), 0, s, inst->d_coord, n,
                                d_starts, (const double *)nullptr, d_vis, d_succ, d_obj, d_status);

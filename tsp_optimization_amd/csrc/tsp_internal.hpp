@@ -77,6 +77,8 @@ struct tsp_dev_inst {
     double org_x = 0.0, org_y = 0.0;   // min corner of the coordinates
     double cost_bound = 1e300;         // no distance of the instance exceeds this (bounding-box diagonal + rounding)
     std::vector<int> h_sinv;           // node -> rank slot
+    void *cons_pool = nullptr;         // scratch of tsp_dev_construct, grown on demand
+    size_t cons_pool_bytes = 0;
     void *d_sxy = nullptr;             // coordinates in rank order (float2 / double2), built on first use by the large greedy
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
 };
