@@ -44,6 +44,20 @@ for c in range(cases):
     rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
     _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
     ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+    if c % 3 == 0 and n >= 8:
+        # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
+        t3 = np.stack([random_tour(n, rng) for _ in range(3)])
+        c3 = np.array([O.succ_cost(xy, wt, t, integer_cost=ic) for t in t3])
+        rc, s3, o3, st3 = inst.two_opt(t3, c3, mode=E.FIRST)
+        for b in range(3):
+            _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
+            ok = ok and (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"]
+        O.srandom(1000 + c)
+        ur = np.array([[O.urand() for _ in range(n)]])
+        O.srandom(1000 + c)
+        _, gs, go = O.grasp(xy, wt, start=s0, integer_cost=ic)
+        sg, og, _ = inst.construct(E.GRASP, np.array([s0], dtype=np.int32), ur)
+        ok = ok and (sg[0] == gs).all() and og[0] == go
     inst.close()
     print("case %d n %d wt %d ic %d %s  %.2f s" % (c, n, wt, ic, "ok" if ok else "MISMATCH", time.perf_counter() - t_case), flush=True)
     if not ok:
