@@ -29,14 +29,11 @@ __global__ __launch_bounds__(kScanThreads) void k_move_recs(const double2 *__res
     const size_t base = (size_t)tour * n;
     const MoveView mv = move_view(st, orders + base, poss + base, orders2 + base, poss2 + base, n);
     const int k = blockIdx.x * kScanThreads + threadIdx.x;
-    if (mv.L > 0 && k < n) {   // new position k
-        int *o_new = (st->parity ? orders : orders2) + base, *p_new = (st->parity ? poss : poss2) + base;
-        const int v = mv.node_at(k);
-        o_new[k] = v;
-        p_new[v] = k;
-    }
-    if (k >= n_slots) return;
-    const int v = sperm[k];
+    // every load (of the current copy, which this kernel never writes) comes before the first store: the compiler
+    // cannot know that the two copies do not overlap and would otherwise finish the move before starting the records
+    const bool copies = mv.L > 0 && k < n;
+    const int moved = copies ? mv.node_at(k) : 0;   // node at new position k
+    const int v = k < n_slots ? sperm[k] : -1;
     NodeRec r;
     if (v >= 0) {
         int ps = mv.pos_of(v) + 1; if (ps == n) ps = 0;
@@ -48,6 +45,12 @@ __global__ __launch_bounds__(kScanThreads) void k_move_recs(const double2 *__res
     } else {   // padding: far away from everything, never passes the new-edge test
         r.x = r.y = r.xs = r.ys = 1e30; r.ds = 0.0; r.succ = -1; r.id = -1;
     }
+    if (copies) {
+        int *o_new = (st->parity ? orders : orders2) + base, *p_new = (st->parity ? poss : poss2) + base;
+        o_new[k] = moved;
+        p_new[moved] = k;
+    }
+    if (k >= n_slots) return;
     recs[(size_t)tour * n_slots + k] = r;
     // the group's longest edge: lengths are >= 0, so they order like their bits and max = ~min(~bits)
     const u64 mb = ~wave_min_u64(~(u64)__double_as_longlong(r.ds));
