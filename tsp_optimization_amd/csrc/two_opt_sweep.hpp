@@ -106,7 +106,7 @@ __device__ __forceinline__ void group_pair(int t, int ng, int &r, int &c) {
     c = rr + (int)(t - ((long long)rr * ng - (long long)rr * (rr - 1) / 2));
 }
 
-constexpr int kSweepCluster = 8;      // blocks that test the same group pairs and deal the survivors among themselves
+constexpr int kSweepCluster = 4;      // blocks that test the same group pairs and deal the survivors among themselves (2-4 measured best)
 constexpr int kSweepRows = 16;        // rows of one unit of wave work (64 / kSweepRows units per group pair)
 constexpr int kSweepStage = 8;        // group pairs whose records a block holds in LDS at a time (6 KB each)
 constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are processed in further passes)
