@@ -65,7 +65,9 @@ enum {
     TSP_ENGINE_AUTO = 0,
     TSP_ENGINE_GRID = 1, /* many workgroups per tour, tour state in HBM, one launch (two for the sorted
                             best-improvement sweep) per step */
-    TSP_ENGINE_LDS = 2   /* one workgroup per tour, whole descent inside one launch, state in LDS */
+    TSP_ENGINE_LDS = 2,  /* one workgroup per tour, whole descent inside one launch, state in LDS */
+    TSP_ENGINE_CLUSTER = 3 /* C workgroups per tour (B C <= #CUs), each with a replica of the tour in LDS, whole
+                            descent inside one launch; one candidate per workgroup and step exchanged through L2 */
 };
 
 typedef struct tsp_dev_ctx tsp_dev_ctx;     /* one device + stream */
@@ -171,6 +173,12 @@ int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t
  * Does not wait for completion unless `sync` != 0.  *all_done (if not NULL, sync only). */
 int tsp_dev_tours_run(tsp_dev_tours *t, int mode, int64_t max_steps, double time_limit_s, int sync,
                       int *all_done);
+/* The same on a chosen engine (TSP_ENGINE_*), always waiting for completion: device-resident tours run to their
+ * local optima (or for at most max_steps steps per tour when max_steps >= 0; not with TSP_ENGINE_LDS).  A capped or
+ * timed-out best-improvement run leaves the recomputed cost in obj like a finished one (src/tabusearch.c:168-172).
+ * TSP_ENGINE_AUTO picks CLUSTER where it applies, else GRID. */
+int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s,
+                             int *all_done);
 /* Launch `reps` best-improvement steps back to back on the current tours (they continue the descent)
  * with HIP events around the run on the engine's stream; returns the mean duration of a step's
  * launches in *mean_ms and the reference-equivalent evaluations per step in *evals_per_launch.

@@ -405,7 +405,7 @@ def test_raw_sqrt_error_budget_of_the_integer_variants(eng, ctx):
 
 
 # ---- both execution engines give the reference's trajectory -----------------------------------
-@pytest.mark.parametrize("engine", [1, 2])          # TSP_ENGINE_GRID, TSP_ENGINE_LDS
+@pytest.mark.parametrize("engine", [1, 2, 3])       # TSP_ENGINE_GRID, TSP_ENGINE_LDS, TSP_ENGINE_CLUSTER
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("name,ic", [("berlin52", 1), ("pr299", 1), ("att532", 1), ("d493", 0), ("d493", 1),
                                      ("dsj1000", 1), ("rand2000", 1)])
@@ -419,7 +419,7 @@ def test_two_opt_engines_match_oracle(eng, ctx, engine, mode, name, ic):
     inst.close()
 
 
-@pytest.mark.parametrize("engine", [1, 2])
+@pytest.mark.parametrize("engine", [1, 2, 3])
 def test_two_opt_engines_random_tours_and_batches(eng, ctx, engine):
     rng = np.random.default_rng(21)
     for n in (5, 6, 17, 64, 65, 300, 1025):

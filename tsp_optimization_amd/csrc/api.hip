@@ -13,6 +13,11 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
                  double time_limit_s, int sync, int *all_done);
 int tsp_lds_run(tsp_dev_tours *t, int mode, double time_limit_s, int *all_done);
 bool tsp_lds_fits(const tsp_dev_inst *inst);
+// two_opt_cluster.hip
+bool tsp_cluster_fits(const tsp_dev_tours *t, int mode);
+bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode);
+int tsp_cluster_size(const tsp_dev_tours *t, int mode);
+int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through);
 
 namespace tsp {
 static thread_local char g_last_error[512] = "";
@@ -270,6 +275,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     if (inst->scratch_b) tsp_dev_tours_destroy(inst->scratch_b);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
     (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy); (void)hipFree(inst->cons_pool);
+    (void)hipFree(inst->d_rcoord); (void)hipFree(inst->d_sinv);
     delete inst;
 }
 
@@ -343,23 +349,8 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
                     int64_t tour_stride, double *obj, double time_limit_s, tsp_two_opt_stats *stats) {
     if (!inst || !succ || !obj || B < 1 || succ_stride < 1) return TSP_DEV_E_ARG;
     if (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST) return TSP_DEV_E_ARG;
-    if (engine != TSP_ENGINE_AUTO && engine != TSP_ENGINE_GRID && engine != TSP_ENGINE_LDS) return TSP_DEV_E_ARG;
+    if (engine < TSP_ENGINE_AUTO || engine > TSP_ENGINE_CLUSTER) return TSP_DEV_E_ARG;
     if (engine == TSP_ENGINE_LDS && !tsp_lds_fits(inst)) return TSP_DEV_E_ARG;
-    if (engine == TSP_ENGINE_AUTO) {
-        // Measured on MI355X (tools/gpu_latency.py, tools/gpu_configs.py): a single tour is always
-        // faster with the whole chip per step (GRID), and BEST batches are a perfect fit for GRID's
-        // grid.z = tour; one workgroup per tour (LDS) wins for FIRST descents of several tours, whose
-        // steps would otherwise be launch-latency bound in lockstep.  Results are identical.
-        const char *force = getenv("TSP_ENGINE");
-        const bool lds_ok = tsp_lds_fits(inst);
-        bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
-        // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
-        // (tools/small_single.py: 15-35 % faster up to pr299, slower from att532 on and on GEO)
-        if (lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299) lds = true;
-        if (force && *force == '1') lds = false;
-        if (force && *force == '2' && lds_ok) lds = true;
-        engine = lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID;
-    }
     const double t0 = wall_s();
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
@@ -369,12 +360,50 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     if (rc) return rc;
     rc = tsp_dev_tours_upload(t, succ, succ_stride, tour_stride, obj);
     if (rc) { if (owned) tsp_dev_tours_destroy(t); return rc; }
+    int cluster_C = 1;
+    if (engine == TSP_ENGINE_CLUSTER) {
+        if (!tsp_cluster_fits(t, mode)) { if (owned) tsp_dev_tours_destroy(t); return TSP_DEV_E_ARG; }
+        cluster_C = tsp_cluster_size(t, mode);
+    }
+    if (engine == TSP_ENGINE_AUTO) {
+        // Measured on MI355X (tools/gpu_latency.py, tools/gpu_configs.py, tools/cluster_time.py).  Results are identical.
+        //  * CLUSTER: tours that fit in a CU's LDS and leave CUs idle (B tours on 256 CUs): C = #CUs / B workgroups per
+        //    tour, whole descent in one launch -- first improvement on any metric, best improvement where the sorted
+        //    scan applies.  A step costs one exchange through L2 instead of one or two kernel boundaries.
+        //  * LDS (one workgroup per tour): first-improvement batches of at least as many tours as half the CUs.
+        //  * GRID: everything else (tours beyond LDS, tabu runs, best improvement on metrics without the new-edge bound).
+        const char *force = getenv("TSP_ENGINE");
+        const bool lds_ok = tsp_lds_fits(inst);
+        const int C = tsp_cluster_fits(t, mode) ? tsp_cluster_size(t, mode) : 0;
+        const bool cl_mode_ok = mode == TSP_2OPT_FIRST || tsp_cluster_sorted(t, mode);
+        bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
+        // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
+        if (lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299) lds = true;
+        bool cluster = C >= 4 && cl_mode_ok;
+        if (force && *force == '1') { lds = false; cluster = false; }
+        if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
+        if (force && *force == '3' && C >= 1) cluster = true;
+        engine = cluster ? TSP_ENGINE_CLUSTER : (lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID);
+        cluster_C = std::max(1, C);
+    }
     if (!inst->ev0) { TSP_HIP_TRY(hipEventCreate(&inst->ev0)); TSP_HIP_TRY(hipEventCreate(&inst->ev1)); }
     hipEvent_t e0 = inst->ev0, e1 = inst->ev1;
     TSP_HIP_TRY(hipEventRecord(e0, s));
     int done = 0;
-    int status = engine == TSP_ENGINE_LDS ? tsp_lds_run(t, mode, time_limit_s, &done)
-                                          : tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
+    int status;
+    if (engine == TSP_ENGINE_CLUSTER) {
+        int fell = 0;
+        status = tsp_cluster_run(t, mode, cluster_C, -1, time_limit_s, &done, &fell);
+        if (fell) {   // a workgroup was not resident (the device is shared): same descent, one launch per step
+            rc = tsp_dev_tours_reset(t);
+            if (rc) { if (owned) tsp_dev_tours_destroy(t); return rc; }
+            status = tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
+        }
+    } else if (engine == TSP_ENGINE_LDS) {
+        status = tsp_lds_run(t, mode, time_limit_s, &done);
+    } else {
+        status = tsp_grid_run(t, mode, nullptr, 0, 0, -1, time_limit_s, 1, &done);
+    }
     TSP_HIP_TRY(hipEventRecord(e1, s));
     TSP_HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -391,6 +420,31 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     }
     if (owned) tsp_dev_tours_destroy(t);
     return rc ? rc : status;
+}
+
+int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
+    if (!t || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    if (all_done) *all_done = 0;
+    if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
+        const bool want = engine == TSP_ENGINE_CLUSTER ||
+                          (tsp_cluster_fits(t, mode) && tsp_cluster_size(t, mode) >= 4 &&
+                           (mode == TSP_2OPT_FIRST || tsp_cluster_sorted(t, mode)));
+        if (want) {
+            if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
+            int fell = 0;
+            const int status = tsp_cluster_run(t, mode, tsp_cluster_size(t, mode), max_steps, time_limit_s, all_done, &fell);
+            if (!fell) return status;
+            if (engine == TSP_ENGINE_CLUSTER) return status;   // asked for explicitly: report, do not substitute
+        }
+        engine = TSP_ENGINE_GRID;
+    }
+    if (engine == TSP_ENGINE_LDS) {
+        if (!tsp_lds_fits(t->inst) || max_steps >= 0) return TSP_DEV_E_ARG;
+        return tsp_lds_run(t, mode, time_limit_s, all_done);
+    }
+    if (engine != TSP_ENGINE_GRID) return TSP_DEV_E_ARG;
+    return tsp_grid_run(t, mode, nullptr, 0, 0, max_steps, time_limit_s, 1, all_done);
 }
 
 }  // extern "C"

@@ -80,6 +80,8 @@ struct tsp_dev_inst {
     void *cons_pool = nullptr;         // scratch of tsp_dev_construct, grown on demand
     size_t cons_pool_bytes = 0;
     void *d_sxy = nullptr;             // coordinates in rank order (float2 / double2), built on first use by the large greedy
+    double2 *d_rcoord = nullptr;       // CLUSTER engine, sorted scan: coordinates in rank order, padding far away (ng * 64)
+    int *d_sinv = nullptr;             // CLUSTER engine, sorted scan: node -> rank slot
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
 };
 
@@ -114,6 +116,12 @@ struct tsp_dev_tours {
     int *d_row_evals = nullptr;
     int max_tile_rows = 0;
     int *d_slot_evals = nullptr;     // per scan block: pairs evaluated (tabu runs only)
+    // CLUSTER engine (two_opt_cluster.hip): exchange area (+ error word) and the group-pair table dealt to cl_C workgroups
+    unsigned long long *d_cl_slots = nullptr;
+    size_t cl_slot_words = 0;
+    int cl_C = 0;
+    int *d_cl_pairtab = nullptr;
+    int cl_ntests = 0;
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;
     std::vector<double> h_obj0;

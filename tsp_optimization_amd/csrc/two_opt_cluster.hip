@@ -1,0 +1,810 @@
+// two_opt_cluster.hip -- CLUSTER engine: C workgroups per tour, the whole 2-opt descent inside one launch.
+//
+// Every workgroup of a tour's cluster keeps a full replica of the tour (coordinates, order[], pos[]) in its CU's LDS,
+// scans its share of the pair space, and the cluster exchanges ONE candidate per workgroup and step through HBM/L2:
+// tagged 8-byte granules, written once with write-through (sc1) stores and swept by one wave of every workgroup until
+// all tags carry the step's epoch (cdna_hip_programming.md Guideline 16, form R2: the data is the flag, no fence).
+// Every workgroup then picks the same winner and applies the same move to its own replica, so the replicas never
+// diverge and a step needs no grid barrier, no kernel boundary and no global tour state.  C = 1 is the degenerate
+// case (no exchange); C = #CUs puts the whole chip on one tour (BASELINE configs[2]); B tours x C workgroups with
+// B C <= #CUs serves multi-start / population shards that would otherwise leave CUs idle (configs[3], [4] on 8 GPUs).
+//
+// Selection rules and semantics are those of the other engines (two_opt_grid.hip header): FIRST = alg_2opt
+// (src/heuristics.c:438-502), BEST = alg_2opt_tabu with skip_edge == NULL (src/tabusearch.c:107-178).
+// Two scans:
+//   tiles   every pair of the scanned rows visited, 32 rows x 512 columns per tile, tiles dealt round-robin to the
+//           cluster's workgroups (FIRST on any metric; BEST on metrics without the new-edge bound);
+//   sorted  BEST on sqrt metrics: nodes renumbered along the Hilbert curve (tsp_dev_inst_create), 64 consecutive
+//           ranks = one group; the box form of the new-edge bound decides 64 x 64 pairs at once, the surviving
+//           group pairs (host-built table, nearest first, dealt round-robin) go through row culling and the
+//           per-pair tiers exactly as in two_opt_sweep.hpp.  Group bound: gmax2[g] = longest tour edge INCIDENT to a
+//           node of g (either direction), which a move changes for at most four groups -- no O(n) rebuild per step.
+// Residency: the cluster protocol needs all B C workgroups on the chip at once; the host launches at most one per CU
+// and every spin is bounded (a workgroup that gives up raises `err`, everybody leaves, the host falls back to GRID).
+#include "two_opt_common.hpp"
+
+#include <algorithm>
+#include <time.h>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace tsp {
+
+constexpr int kClThreads = 512;
+constexpr int kClWaves = kClThreads / 64;
+constexpr int kClRows = 32;        // rows of one tile
+constexpr int kClListCap = 1024;   // surviving group pairs a workgroup holds at a time
+constexpr int kClUnitRows = 16;    // rows of one unit of wave work in the sorted scan
+constexpr int kClSlotGranules = 4; // granules per workgroup and parity in the exchange area
+constexpr unsigned kClSpinLimit = 1u << 20;   // sweeps of the exchange area before a workgroup gives up (~ seconds)
+using idx_t = unsigned short;
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gi32c = __attribute__((address_space(1))) int;
+
+struct ClusterArgs {
+    const double2 *coord;   // internal numbering: node order (tiles) or Hilbert rank order incl. padding (sorted)
+    int *orders;            // B x n: node (caller's numbering) at tour position p
+    TourState *states;
+    const int *gid;         // sorted: internal id -> node
+    const int *iid;         // sorted: node -> internal id
+    const double4 *gbox;    // sorted: group boxes {min x, max x, min y, max y}
+    const int *pairtab;     // sorted: C x ntests group pairs (r << 16 | c, -1 = none), nearest first, dealt in turn
+    unsigned long long *slots;   // B x 2 x C x kClSlotGranules
+    int *err;
+    int n, nid, ng, ntests, C, max_iters, rmin, rmax, count_evals;
+    int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
+    double org_x, org_y;    // float replicas hold coordinates relative to this corner (exact: bounded integers)
+    double margin, prune, sum_margin;
+};
+
+template <typename CT> struct ClCoord;
+template <> struct ClCoord<double2> {
+    static __device__ __forceinline__ double2 make(double2 c, double, double) { return c; }
+    static __device__ __forceinline__ double4 box(double4 b, double, double) { return b; }
+};
+template <> struct ClCoord<float2> {
+    static __device__ __forceinline__ float2 make(double2 c, double ox, double oy) {
+        return make_float2((float)(c.x - ox), (float)(c.y - oy));
+    }
+    // group boxes live in the replica's frame too ({min x, max x, min y, max y}; integer coordinates: exact)
+    static __device__ __forceinline__ double4 box(double4 b, double ox, double oy) {
+        return make_double4(b.x - ox, b.y - ox, b.z - oy, b.w - oy);
+    }
+};
+
+__host__ __device__ inline size_t cl_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS carve-up (host and device agree through this one function)
+struct ClLayout {
+    size_t coord, order, pos, gbox, gmax, urows, list, rows, scratch, total;
+};
+__host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted) {
+    ClLayout L;
+    size_t o = 0;
+    L.coord = o; o = cl_align16(o + coord_elem * (size_t)nid);
+    L.order = o; o = cl_align16(o + sizeof(idx_t) * (size_t)n);
+    L.pos = o; o = cl_align16(o + sizeof(idx_t) * (size_t)nid);
+    L.gbox = L.gmax = L.urows = L.list = L.rows = o;
+    if (sorted) {
+        L.gbox = o; o = cl_align16(o + sizeof(double4) * (size_t)ng);
+        L.gmax = o; o = cl_align16(o + sizeof(double) * (size_t)ng);
+        L.urows = o; o = cl_align16(o + sizeof(NodeRec) * kClUnitRows * kClWaves);
+        L.list = o; o = cl_align16(o + sizeof(int) * kClListCap);
+    } else {
+        L.rows = o; o = cl_align16(o + sizeof(NodeRec) * kClRows);
+    }
+    L.scratch = o; o += 1024;
+    L.total = o;
+    return L;
+}
+
+template <int WT, bool INT, typename CT>
+__device__ __forceinline__ NodeRec cl_node(const CT *coord, const idx_t *order, const idx_t *pos, int n, int v) {
+    const int p = (int)pos[v];
+    const int q = p + 1 == n ? 0 : p + 1;
+    const int s = (int)order[q];
+    const CT c = coord[v], cs = coord[s];
+    NodeRec r;
+    r.x = (double)c.x; r.y = (double)c.y; r.xs = (double)cs.x; r.ys = (double)cs.y;
+    r.ds = dist_xy<WT, INT>(r.x, r.y, r.xs, r.ys);
+    r.succ = s; r.id = v;
+    return r;
+}
+
+template <int WT, bool INT, typename CT>
+__device__ __forceinline__ double cl_dist(const CT *coord, int u, int v) {
+    const CT a = coord[u], b = coord[v];
+    return dist_xy<WT, INT>((double)a.x, (double)a.y, (double)b.x, (double)b.y);
+}
+
+__device__ __forceinline__ double cl_lane_bcast(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// max over the 64 lanes of a non-negative double (orders like its bits)
+__device__ __forceinline__ double cl_wave_max_nonneg(double v) {
+    const u64 mb = ~wave_min_u64(~(u64)__double_as_longlong(v));
+    return __longlong_as_double((long long)mb);
+}
+
+// One workgroup's candidate of a step.  key: the pair in the caller's node numbering (lower id first; kNoKey = none),
+// ipair: the same two nodes in internal numbering, (node of the lower id) << 16 | (the other one).
+struct ClCand {
+    double d;
+    u64 key;
+    unsigned ipair;
+};
+
+// ---- the exchange: one candidate per workgroup and step -------------------------------------------------------
+// Producer: lane 0 of the workgroup, four 8-byte sc1 stores {epoch, payload} into the workgroup's slot of the
+// step's parity.  Consumer: wave 0 of every workgroup sweeps all C slots with sc1 loads until every tag carries the
+// epoch.  Two parities: a workgroup can be at most one step ahead of the slowest one (it cannot finish step s + 1
+// before everybody has published s + 1, i.e. has finished reading s), so slot parity s is never rewritten while
+// somebody still reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
+template <bool BEST>
+__device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err) {
+    const int lane = threadIdx.x & 63;
+    const u64 tag = (u64)ep << 32;
+    gu64 *par = area + (size_t)(ep & 1u) * C * kClSlotGranules;
+    if (lane == 0) {
+        gu64 *my = par + (size_t)c * kClSlotGranules;
+        const u64 db = (u64)__double_as_longlong(cd.d);
+        const unsigned kp = cd.key == kNoKey ? 0xffffffffu : (((unsigned)key_i(cd.key) & 0xffffu) << 16) | ((unsigned)key_j(cd.key) & 0xffffu);
+        __hip_atomic_store(my + 0, tag | kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my + 1, tag | cd.ipair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my + 2, tag | (db & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my + 3, tag | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    constexpr int Q = 4;   // C <= 256: at most four slots per lane
+    u64 g[Q][kClSlotGranules];
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int k = q * 64 + lane;
+            if (k < C) {
+#pragma unroll
+                for (int w = 0; w < kClSlotGranules; ++w)
+                    g[q][w] = __hip_atomic_load(par + (size_t)k * kClSlotGranules + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int w = 0; w < kClSlotGranules; ++w) ok = ok && (g[q][w] >> 32) == (u64)ep;
+            }
+        }
+        if (__all(ok)) break;
+        if (++spins > kClSpinLimit ||
+            ((spins & 1023u) == 0 && __hip_atomic_load((gi32c *)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            if (lane == 0) __hip_atomic_store((gi32c *)err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    double bd = 0.0;
+    u64 key = kNoKey;
+    unsigned ip = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int k = q * 64 + lane;
+        if (k < C) {
+            const unsigned kp = (unsigned)g[q][0];
+            if (kp != 0xffffffffu) {
+                const u64 kk = make_key((int)(kp >> 16), (int)(kp & 0xffffu));
+                const double d = __longlong_as_double((long long)((g[q][2] & 0xffffffffull) | (g[q][3] << 32)));
+                const bool take = BEST ? better(d, kk, bd, key) : (kk < key);
+                if (key == kNoKey || take) { bd = d; key = kk; ip = (unsigned)g[q][1]; }
+            }
+        }
+    }
+    double wd = bd;
+    u64 wk = key;
+    wave_argmin<BEST>(wd, wk);
+    // the winner's internal pair rides along: a pair is evaluated by exactly one lane of one workgroup
+    const unsigned long long owners = __ballot(key == wk && wk != kNoKey);
+    unsigned wip = 0;
+    if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
+    cd.d = wd; cd.key = wk; cd.ipair = wip;
+    return true;
+}
+
+template <int WT, bool INT, int MODE, typename CT, bool SORTED>
+__global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArgs a) {
+    static_assert(!SORTED || (MODE == TSP_2OPT_BEST && has_root_filter<WT>()), "the sorted scan is a best-improvement sweep on a sqrt metric");
+    constexpr bool BEST = MODE == TSP_2OPT_BEST;
+    constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = a.n, nid = a.nid, ng = a.ng, C = a.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tour = (int)blockIdx.x / C, c = (int)blockIdx.x % C;
+    const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED);
+    CT *coord = reinterpret_cast<CT *>(smem + L.coord);
+    idx_t *order = reinterpret_cast<idx_t *>(smem + L.order);
+    idx_t *pos = reinterpret_cast<idx_t *>(smem + L.pos);
+    double4 *gbox = reinterpret_cast<double4 *>(smem + L.gbox);
+    double *gmax = reinterpret_cast<double *>(smem + L.gmax);
+    NodeRec *s_urows = reinterpret_cast<NodeRec *>(smem + L.urows);
+    int *s_list = reinterpret_cast<int *>(smem + L.list);
+    NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem + L.rows);
+    char *scratch = smem + L.scratch;
+    double *s_d = reinterpret_cast<double *>(scratch);                 // 16
+    u64 *s_k = reinterpret_cast<u64 *>(scratch + 128);                 // 16
+    long long *s_ll = reinterpret_cast<long long *>(scratch + 256);    // 16
+    int *s_wcount = reinterpret_cast<int *>(scratch + 384);            // 16 ints
+    double *s_win_d = reinterpret_cast<double *>(scratch + 448);
+    u64 *s_win_k = reinterpret_cast<u64 *>(scratch + 456);
+    unsigned *s_win_ip = reinterpret_cast<unsigned *>(scratch + 464);
+    int *s_fail = reinterpret_cast<int *>(scratch + 468);
+    unsigned *s_blk_ip = reinterpret_cast<unsigned *>(scratch + 472);   // the workgroup's own winner (before the exchange)
+    double *s_chunk = reinterpret_cast<double *>(scratch + 512);       // 64 doubles (fcost cost recompute)
+
+    TourState *st = a.states + tour;
+    if (st->done) return;
+    int *order_g = a.orders + (size_t)tour * n;
+    gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * C * kClSlotGranules;
+
+    for (int v = tid; v < nid; v += kClThreads) coord[v] = ClCoord<CT>::make(a.coord[v], a.org_x, a.org_y);
+    for (int p = tid; p < n; p += kClThreads) {
+        int w = order_g[p];
+        if constexpr (SORTED) w = a.iid[w];
+        order[p] = (idx_t)w;
+        pos[w] = (idx_t)p;
+    }
+    if constexpr (SORTED) {
+        for (int g = tid; g < ng; g += kClThreads) gbox[g] = ClCoord<CT>::box(a.gbox[g], a.org_x, a.org_y);
+    }
+    if (tid == 0) *s_fail = 0;
+    int ci = st->ci, cj = st->cj, chunk = min(max(st->chunk_rows, 1), a.rmax), done = 0;
+    double obj = st->obj, seen = st->seen_cost;
+    long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
+              scanned = st->pairs_scanned, steps = st->steps;
+    __syncthreads();
+
+    // longest tour edge incident to a node of group g, for the groups g0, g0 + stride, ... (one wave per group)
+    auto group_bounds = [&](int g0, int stride, int gend) {
+        for (int g = g0; g < gend; g += stride) {
+            const int v = g * 64 + lane;
+            double m = 0.0;
+            if (v < n) {
+                const int p = (int)pos[v];
+                const int su = (int)order[p + 1 == n ? 0 : p + 1], pr = (int)order[p == 0 ? n - 1 : p - 1];
+                m = fmax(cl_dist<WT, INT, CT>(coord, v, su), cl_dist<WT, INT, CT>(coord, v, pr));
+            }
+            m = cl_wave_max_nonneg(m);
+            if (lane == 0) gmax[g] = m;
+        }
+    };
+    if constexpr (SORTED) {
+        group_bounds(wave, kClWaves, ng);
+        __syncthreads();
+    }
+
+    const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
+    bool failed = false;
+    for (int iter = 0; iter < a.max_iters && !done; ++iter) {
+        int row_lo = 0, row_hi = n - 1;
+        if constexpr (!BEST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
+        double bd = 0.0;
+        u64 key = kNoKey;
+        unsigned ipair = 0;
+
+        if constexpr (SORTED) {
+            // ---- sorted scan: box tests on this workgroup's share of the group pairs, then the survivors ------
+            const int *tab = a.pairtab + (size_t)c * a.ntests;
+            int m0 = 0;
+            while (m0 < a.ntests) {
+                int kept = 0;
+                while (m0 < a.ntests && kept + kClThreads <= kClListCap) {
+                    const int m = m0 + tid;
+                    const int e = m < a.ntests ? tab[m] : -1;
+                    bool surv = false;
+                    if (e >= 0) {
+                        const int r = e >> 16, cg = e & 0xffff;
+                        const double4 rb = gbox[r], cb = gbox[cg];
+                        const double gx = fmax(0.0, fmax(rb.x - cb.y, cb.x - rb.y)), gy = fmax(0.0, fmax(rb.z - cb.w, cb.z - rb.w));
+                        const double T = gmax[r] + gmax[cg] + prune2;   // bound 0: nothing is known about this sweep yet
+                        surv = gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+                        if (a.dbg & 4) surv = true;
+                    }
+                    const unsigned long long bal = __ballot(surv);
+                    if (lane == 0) s_wcount[wave] = __popcll(bal);
+                    __syncthreads();
+                    int before = 0, total = 0;
+#pragma unroll
+                    for (int w = 0; w < kClWaves; ++w) { const int cw = s_wcount[w]; before += (w < wave) ? cw : 0; total += cw; }
+                    if (surv) s_list[kept + before + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+                    kept += total;
+                    m0 += kClThreads;
+                    __syncthreads();
+                }
+                // units of 16 rows x 64 columns, dealt to the waves in turn; the waves share nothing until the arg-min
+                constexpr int UPP = 64 / kClUnitRows;
+                NodeRec *rows = s_urows + wave * kClUnitRows;
+                for (int u = wave; u < UPP * kept; u += kClWaves) {
+                    const int e = s_list[u / UPP];
+                    const int r = e >> 16, cgp = e & 0xffff, row0 = (u % UPP) * kClUnitRows;
+                    const int cslot = cgp * 64 + lane, rslot = r * 64 + row0 + (lane & (kClUnitRows - 1));
+                    NodeRec rj, rr;
+                    rj.x = rj.y = rj.xs = rj.ys = 1e30; rj.ds = 0.0; rj.succ = -1; rj.id = -1;   // padding: far from everything
+                    rr = rj;
+                    if (cslot < n) rj = cl_node<WT, INT, CT>(coord, order, pos, n, cslot);
+                    if (rslot < n) rr = cl_node<WT, INT, CT>(coord, order, pos, n, rslot);
+                    if (lane < kClUnitRows) rows[lane] = rr;   // tiers 1 and 2 read whole row records (same wave: LDS keeps order)
+                    const double cds = rj.ds + prune2, cds2 = rj.ds + a.sum_margin;
+                    double bound = bd;   // the lane's own best so far
+                    // rows that cannot reach the column group's box at all are dropped for the whole wave
+                    unsigned alive;
+                    const double hx = rr.x, hy = rr.y, hd = rr.ds;
+                    {
+                        const double4 cb = gbox[cgp];
+                        const double cmax = cl_wave_max_nonneg(rj.ds);   // longest edge leaving one of these columns
+                        const double gx = fmax(0.0, fmax(cb.x - rr.x, rr.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rr.y, rr.y - cb.w));
+                        const double T = rr.ds + cmax + prune2;
+                        const bool reach = lane < kClUnitRows && ((a.dbg & 2) || gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T));
+                        alive = __builtin_amdgcn_readfirstlane((unsigned)__ballot(reach));
+                    }
+                    auto rare4 = [&](const int (&idx)[4], const bool (&need)[4]) {
+                        // tier 1, both new edges, no root: |ab| + |a1 b1| < T2 = bound + d(a,a1) + d(b,b1) + margin
+                        //   <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2
+                        bool ok[4];
+                        bool any2 = false;
+                        NodeRec ri[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ri[q] = rows[idx[q]];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const double dx1 = ri[q].x - rj.x, dy1 = ri[q].y - rj.y;
+                            const double dx = ri[q].xs - rj.xs, dy = ri[q].ys - rj.ys, T2 = ri[q].ds + bound + cds2;
+                            const double sc = ATT10 ? 0.1 : 1.0;
+                            const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
+                            const double w = T2 * T2 - p1 - p2;
+                            ok[q] = need[q] & (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
+                                    ((cgp > r) | (row0 + idx[q] < lane)) & (ri[q].id >= 0) & (rj.id >= 0) &
+                                    (rj.id != ri[q].succ) & (rj.succ != ri[q].id);
+                            any2 = any2 | ok[q];
+                        }
+                        if (any2) {   // tier 2: the exact delta, lower node id first (tabusearch.c:150 with i < j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (ok[q]) {
+                                    int gi = 0, gj = 0;
+                                    double delta;
+                                    if constexpr (INT) {
+                                        delta = pair_delta<WT, INT>(ri[q], rj);   // integer-valued terms: the sum is exact in any order
+                                    } else {
+                                        gi = a.gid[ri[q].id]; gj = a.gid[rj.id];
+                                        delta = gi < gj ? pair_delta<WT, INT>(ri[q], rj) : pair_delta<WT, INT>(rj, ri[q]);
+                                    }
+                                    if (delta < bd || (delta == bd && delta < 0.0)) {
+                                        if constexpr (INT) { gi = a.gid[ri[q].id]; gj = a.gid[rj.id]; }
+                                        const u64 kk = make_key(min(gi, gj), max(gi, gj));
+                                        if (delta < bd || kk < key) {
+                                            bd = delta; key = kk; bound = bd;
+                                            ipair = gi < gj ? (((unsigned)ri[q].id << 16) | (unsigned)rj.id)
+                                                            : (((unsigned)rj.id << 16) | (unsigned)ri[q].id);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    while (alive) {
+                        int idx[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (alive) { idx[q] = __builtin_ctz(alive); alive &= alive - 1; }
+                            else idx[q] = idx[q > 0 ? q - 1 : 0];
+                        }
+                        bool need[4];
+                        bool any = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin
+                            const double rx = cl_lane_bcast(hx, idx[q]), ry = cl_lane_bcast(hy, idx[q]), rd = cl_lane_bcast(hd, idx[q]);
+                            const double dx = rx - rj.x, dy = ry - rj.y, T = rd + bound + cds;
+                            need[q] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);   // T <= 0: never
+                            any = any || need[q];
+                        }
+                        if (any) rare4(idx, need);
+                    }
+                }
+                __syncthreads();   // the list is rewritten by the next pass
+            }
+        } else {
+            // ---- tiles: 32 rows x 512 columns, tile t = row block * nb + column batch, dealt round-robin ---------
+            const int nb = (n + kClThreads - 1) / kClThreads;
+            const int nrb = (row_hi - row_lo + kClRows - 1) / kClRows;
+            int hit_rb = nrb;   // FIRST: first row block in which this workgroup has found an improving pair
+            bool any_hit = false;
+            for (int t = c; t < nrb * nb; t += C) {
+                const int rbi = t / nb, b = t - rbi * nb;
+                if (!BEST && rbi > hit_rb) break;   // later rows only hold later pairs
+                const int rb = row_lo + rbi * kClRows;
+                const int nr = min(kClRows, row_hi - rb);
+                const int j = b * kClThreads + tid;
+                // no column of this batch above the first row (or, in the cursor's row alone, above the cursor)
+                const int jmin = (!BEST && nr == 1 && rb == ci) ? max(rb, cj) : rb;
+                if (b * kClThreads + kClThreads - 1 <= jmin) continue;
+                __syncthreads();
+                if (tid < nr) s_rows[tid] = cl_node<WT, INT, CT>(coord, order, pos, n, rb + tid);
+                NodeRec rj;
+                const bool act = j < n && j > rb;
+                if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
+                __syncthreads();
+                if (act) {
+                    for (int r = 0; r < nr; ++r) {
+                        const int i = rb + r;
+                        const NodeRec ri = s_rows[r];
+                        bool ok = j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                        if constexpr (!BEST) ok = ok && (i > ci || j > cj);
+                        const u64 kq = make_key(i, j);
+                        if constexpr (!BEST) ok = ok && kq < key;
+                        if constexpr (has_root_filter<WT>()) {
+                            const double bound = BEST ? bd : 0.0;
+                            ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + prune2);
+                            if (ok) {
+                                const double lower = pair_delta_approx<WT>(ri, rj) - a.margin;
+                                ok = BEST ? lower <= bound : lower < bound;
+                            }
+                        }
+                        if (ok) {
+                            const double delta = pair_delta<WT, INT>(ri, rj);
+                            if constexpr (!BEST) {
+                                if (delta < 0) { bd = delta; key = kq; }
+                            } else {
+                                if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                            }
+                        }
+                    }
+                }
+                if constexpr (!BEST) {
+                    if (!any_hit && __syncthreads_or(key != kNoKey)) { any_hit = true; hit_rb = rbi; }
+                }
+            }
+            if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
+        }
+
+        // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
+        {
+            const u64 mykey = key;
+            block_argmin<BEST>(bd, key, s_d, s_k);
+            if constexpr (SORTED) {
+                if (mykey == key && key != kNoKey) *s_blk_ip = ipair;   // exactly one thread evaluated the winning pair
+                __syncthreads();
+                if (key != kNoKey) ipair = *s_blk_ip;
+            } else if (key != kNoKey) {
+                ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
+            }
+        }
+        if (C > 1) {
+            if (wave == 0) {
+                ClCand cd{bd, key, ipair};
+                const bool okx = cl_exchange<BEST>(area, C, c, (unsigned)(iter + 1), cd, a.err);
+                if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
+            }
+            __syncthreads();
+            if (*s_fail) { failed = true; break; }
+            bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        }
+        const bool found = key != kNoKey && (!BEST || bd < 0);
+        const int wi = found ? (int)(ipair >> 16) : -1, wj = found ? (int)(ipair & 0xffffu) : -1;   // internal ids
+
+        // ---- reference-equivalent evaluation count (FIRST; kept by the cluster's first workgroup) ----------------
+        long long adj = 0;
+        int ni = wi, nj = wj;
+        if constexpr (!BEST) {
+            if (!found) { ni = row_hi - 1; nj = n - 1; }
+            if (a.count_evals && c == 0) {
+                const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
+                long long cnt = 0;
+                for (int r = ci + tid; r <= ni; r += kClThreads) {
+                    const int p = pos[r];
+                    const int s = order[p + 1 == n ? 0 : p + 1], q = order[p == 0 ? n - 1 : p - 1];
+                    const u64 ks = make_key(r, s), kq = make_key(r, q);
+                    cnt += (s > r && ks > lo && ks <= hi) ? 1 : 0;
+                    cnt += (q > r && kq > lo && kq <= hi) ? 1 : 0;
+                }
+                adj = block_sum<long long>(cnt, s_ll);
+            }
+        }
+
+        // ---- move: reverse positions pa+1 .. pb (cyclic), src/utility.c:708-717 ------------------------------------
+        int Lr = 0;
+        if (found) {
+            const int pa = pos[wi], pb = pos[wj];
+            int ga1 = 0, gb1 = 0;
+            if constexpr (SORTED) {
+                ga1 = (int)order[pa + 1 == n ? 0 : pa + 1] >> 6;
+                gb1 = (int)order[pb + 1 == n ? 0 : pb + 1] >> 6;
+            }
+            __syncthreads();   // everyone has read pa / pb (and finished the adjacency reads)
+            Lr = pb - pa; if (Lr < 0) Lr += n;
+            const int half = Lr >> 1;
+            for (int t = tid; t < half; t += kClThreads) {
+                int p = pa + 1 + t; if (p >= n) p -= n;
+                int q = pb - t; if (q < 0) q += n;
+                const idx_t u = order[p], w = order[q];
+                order[p] = w; order[q] = u;
+                pos[w] = (idx_t)p; pos[u] = (idx_t)q;
+            }
+            if constexpr (SORTED) {
+                __syncthreads();
+                // the move changes the incident edges of a, succ a, b, succ b only: their groups' bounds are rebuilt
+                if (a.dbg & 1) {
+                    group_bounds(wave, kClWaves, ng);
+                } else if (wave < 4) {
+                    const int g = wave == 0 ? (wi >> 6) : (wave == 1 ? (wj >> 6) : (wave == 2 ? ga1 : gb1));
+                    group_bounds(g, 1, g + 1);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- control block ------------------------------------------------------------------------------------------
+        steps += 1;
+        if constexpr (BEST) {
+            sweeps += 1;
+            evals += (long long)n * (n - 1) / 2 - n;
+            scanned += (long long)n * (n - 1) / 2;
+            if (found) { moves += 1; reversed += Lr - 1; }
+            else {
+                done = 1;
+                // recomputed cost in node order (tabusearch.c:168-172); only the first workgroup reports it
+                if (c == 0) {
+                    if constexpr (INT || WT == WT_CEIL_2D) {
+                        double cc = 0.0;
+                        for (int v = tid; v < n; v += kClThreads) cc += cl_node<WT, INT, CT>(coord, order, pos, n, v).ds;
+                        obj = block_sum<double>(cc, s_d);
+                    } else {
+                        double acc = 0.0;
+                        for (int base = 0; base < n; base += 64) {   // sequential order, 64 edges at a time
+                            __syncthreads();
+                            if (tid < 64 && base + tid < n) {
+                                int v = base + tid;
+                                if constexpr (SORTED) v = a.iid[v];
+                                s_chunk[tid] = cl_node<WT, INT, CT>(coord, order, pos, n, v).ds;
+                            }
+                            __syncthreads();
+                            const int m = min(64, n - base);
+                            for (int t = 0; t < m; ++t) acc += s_chunk[t];
+                        }
+                        obj = acc;
+                    }
+                }
+            }
+        } else {
+            const long long r_old = pair_rank(ci, cj, n);
+            scanned += pair_rank(row_hi - 1, n - 1, n) - r_old;
+            evals += pair_rank(ni, nj, n) - r_old - adj;
+            if (found) {
+                obj += bd;                              // heuristics.c:486
+                moves += 1; reversed += Lr - 1;
+                ci = wi; cj = wj; chunk = a.rmin;
+            } else {
+                chunk = min(chunk * 2, a.rmax);
+                if (row_hi >= n - 1) {                  // sweep complete
+                    sweeps += 1;
+                    if (obj >= seen) done = 1;          // heuristics.c:492
+                    else { seen = obj; ci = 0; cj = 0; }
+                } else { ci = row_hi - 1; cj = n - 1; }
+            }
+        }
+    }
+
+    // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
+    if (failed || c != 0) return;
+    __syncthreads();
+    for (int p = tid; p < n; p += kClThreads) {
+        int v = (int)order[p];
+        if constexpr (SORTED) v = a.gid[v];
+        order_g[p] = v;
+    }
+    if (tid == 0) {
+        st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
+        st->sweeps = sweeps; st->evals = evals; st->moves = moves; st->reversed = reversed;
+        st->pairs_scanned = scanned; st->steps = steps;
+        st->parity = 0; st->pending = 0;
+    }
+}
+
+}  // namespace tsp
+
+using namespace tsp;
+
+namespace {
+double wall_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+constexpr size_t kLdsLimit = (size_t)160 * 1024;
+
+// ICOORD variants: coordinates are integers of bounded span -> exact as floats relative to the instance corner
+template <int WT>
+constexpr bool cl_float_coords() {
+    return WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
+}
+
+struct ClPlan {
+    bool ok = false, sorted = false, float_coords = false;
+    size_t lds = 0;
+    int nid = 0;
+};
+
+// Which scan a run in `mode` uses on this handle, and whether the replica fits in LDS.
+ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
+    ClPlan p;
+    const tsp_dev_inst *inst = t->inst;
+    if (inst->n > 65534) return p;
+    const int wt = inst->wtype;
+    p.float_coords = wt == WT_EUC_2D_ICOORD || wt == WT_CEIL_2D_ICOORD || wt == WT_ATT_ICOORD;
+    p.sorted = mode == TSP_2OPT_BEST && inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
+               inst->n >= t->sorted_min_n;
+    p.nid = p.sorted ? inst->ng * 64 : inst->n;
+    p.lds = cl_layout(inst->n, p.nid, inst->ng, p.float_coords ? sizeof(float2) : sizeof(double2), p.sorted).total;
+    p.ok = p.lds <= kLdsLimit;
+    return p;
+}
+
+template <int WT, bool INT, int MODE, typename CT, bool SORTED>
+hipError_t cl_launch_k(tsp_dev_tours *t, const ClusterArgs &a, size_t lds) {
+    hipStream_t s = t->inst->ctx->stream;
+    auto k = k_cluster_two_opt<WT, INT, MODE, CT, SORTED>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(t->B * a.C), dim3(kClThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int WT, bool INT>
+hipError_t cl_launch(tsp_dev_tours *t, int mode, const ClPlan &p, const ClusterArgs &a) {
+    using CT = std::conditional_t<cl_float_coords<WT>(), float2, double2>;
+    if (mode == TSP_2OPT_FIRST) return cl_launch_k<WT, INT, TSP_2OPT_FIRST, CT, false>(t, a, p.lds);
+    if constexpr (has_root_filter<WT>()) {
+        if (p.sorted) return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, true>(t, a, p.lds);
+    }
+    return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, false>(t, a, p.lds);
+}
+}  // namespace
+
+// implemented in two_opt_grid.hip
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+
+bool tsp_cluster_fits(const tsp_dev_tours *t, int mode) { return t && cl_plan(t, mode).ok; }
+bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode) { return t && cl_plan(t, mode).sorted; }
+
+// Cluster size for B tours on this device: one workgroup per CU at most, whole clusters only.
+int tsp_cluster_size(const tsp_dev_tours *t, int mode) {
+    const int cus = std::max(1, t->inst->ctx->num_cus);
+    int C = std::max(1, std::min(256, cus / std::max(1, t->B)));
+    const ClPlan p = cl_plan(t, mode);
+    if (p.sorted) {   // no more workgroups than a few group pairs each
+        const long long npairs = (long long)t->inst->ng * (t->inst->ng + 1) / 2;
+        C = (int)std::max<long long>(1, std::min<long long>(C, (npairs + 3) / 4));
+    } else {
+        const long long nb = (t->n + kClThreads - 1) / kClThreads, nrb = (t->n - 1 + kClRows - 1) / kClRows;
+        C = (int)std::max<long long>(1, std::min<long long>(C, nb * nrb));
+    }
+    return std::max(1, env_int("TSP_CLUSTER_BLOCKS", C));
+}
+
+// Runs the tours of `t` to their local optima with C workgroups per tour.  Returns TSP_DEV_E_HIP with
+// *fell_through = 1 when the cluster protocol gave up (a workgroup was not resident): the tours in HBM are
+// then exactly as uploaded by the last launch that completed and the caller may continue with another engine.
+// max_steps >= 0 caps the steps per tour (a capped best-improvement run gets its recomputed cost like a timed-out one).
+int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through) {
+    if (fell_through) *fell_through = 0;
+    if (all_done) *all_done = 0;
+    if (!t || C < 1 || C > 256) return TSP_DEV_E_ARG;
+    const ClPlan p = cl_plan(t, mode);
+    if (!p.ok) return TSP_DEV_E_ARG;
+    tsp_dev_inst *inst = t->inst;
+    hipStream_t s = inst->ctx->stream;
+    const int n = t->n, B = t->B;
+    if (C > 1 && (long long)B * C > std::max(1, inst->ctx->num_cus)) return TSP_DEV_E_ARG;   // all workgroups must be resident
+
+    // per-instance tables of the sorted scan: coordinates in rank order (padding far away), node -> rank
+    if (p.sorted && !inst->d_rcoord) {
+        std::vector<double2> rc((size_t)p.nid);
+        std::vector<int> sperm((size_t)inst->n_slots);
+        TSP_HIP_TRY(hipMemcpy(sperm.data(), inst->d_sperm, sizeof(int) * sperm.size(), hipMemcpyDeviceToHost));
+        for (int k = 0; k < p.nid; ++k) {
+            const int v = sperm[k];
+            rc[k] = v >= 0 ? make_double2(inst->h_xy[2 * (size_t)v], inst->h_xy[2 * (size_t)v + 1]) : make_double2(1e30, 1e30);
+        }
+        TSP_HIP_TRY(hipMalloc(&inst->d_rcoord, sizeof(double2) * rc.size()));
+        TSP_HIP_TRY(hipMemcpy(inst->d_rcoord, rc.data(), sizeof(double2) * rc.size(), hipMemcpyHostToDevice));
+        TSP_HIP_TRY(hipMalloc(&inst->d_sinv, sizeof(int) * (size_t)n));
+        TSP_HIP_TRY(hipMemcpy(inst->d_sinv, inst->h_sinv.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    // per-handle: exchange area, error word, and the group-pair table dealt to C workgroups
+    if (t->cl_C != C || !t->d_cl_slots) {
+        (void)hipFree(t->d_cl_slots); t->d_cl_slots = nullptr;
+        (void)hipFree(t->d_cl_pairtab); t->d_cl_pairtab = nullptr;
+        t->cl_ntests = 0;
+        const size_t words = (size_t)B * 2 * C * kClSlotGranules + 2;   // + the error word
+        TSP_HIP_TRY(hipMalloc(&t->d_cl_slots, sizeof(unsigned long long) * words));
+        t->cl_slot_words = words;
+        t->cl_C = C;
+    }
+    if (p.sorted && !t->d_cl_pairtab) {
+        const int ng = inst->ng;
+        const long long npairs = (long long)ng * (ng + 1) / 2;
+        const long long ntests = (npairs + C - 1) / C;
+        std::vector<std::pair<double, int>> pr((size_t)npairs);
+        size_t w = 0;
+        for (int r = 0; r < ng; ++r)
+            for (int cg = r; cg < ng; ++cg) {
+                const double4 &rb = inst->h_gbox[r], &cb = inst->h_gbox[cg];
+                const double gx = std::max(0.0, std::max(rb.x - cb.y, cb.x - rb.y)), gy = std::max(0.0, std::max(rb.z - cb.w, cb.z - rb.w));
+                pr[w++] = {gx * gx + gy * gy, (r << 16) | cg};
+            }
+        std::sort(pr.begin(), pr.end());
+        std::vector<int> tab((size_t)C * ntests, -1);
+        for (long long k = 0; k < npairs; ++k) tab[(size_t)(k % C) * ntests + (size_t)(k / C)] = pr[(size_t)k].second;
+        TSP_HIP_TRY(hipMalloc(&t->d_cl_pairtab, tab.size() * sizeof(int)));
+        TSP_HIP_TRY(hipMemcpy(t->d_cl_pairtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        t->cl_ntests = (int)ntests;
+    }
+
+    ClusterArgs a;
+    a.coord = p.sorted ? inst->d_rcoord : inst->d_coord;
+    a.orders = t->d_order; a.states = t->d_state;
+    a.gid = p.sorted ? inst->d_sperm : nullptr;
+    a.iid = p.sorted ? inst->d_sinv : nullptr;
+    a.gbox = inst->d_gbox;
+    a.pairtab = t->d_cl_pairtab;
+    a.slots = t->d_cl_slots;
+    a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
+    a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
+    a.count_evals = t->count_evals;
+    a.dbg = env_int("TSP_CLUSTER_DEBUG", 0);
+    a.org_x = inst->org_x; a.org_y = inst->org_y;
+    a.margin = inst->filter_margin; a.prune = inst->prune_margin; a.sum_margin = inst->sum_margin;
+    // FIRST chunk geometry: a step costs a few microseconds whatever it scans, so the smallest chunk grows with the
+    // cluster (about 4000 pairs per workgroup), the largest keeps every workgroup busy for a few tiles
+    const long long per_step = 4000ll * C;
+    const int auto_rmin = (int)std::max<long long>(1, std::min<long long>(64, (per_step + n / 2) / n));
+    a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", auto_rmin)));
+    a.rmax = std::max(a.rmin, std::min(2048, env_int("TSP_CLUSTER_MAX_ROWS", C == 1 ? kClRows : std::max(kClRows, 8 * C))));
+    const int launch_iters = mode == TSP_2OPT_FIRST ? 16384 : 4096;   // steps per launch (a time limit is honoured between launches)
+
+    const double t0 = wall_s();
+    int status = TSP_OK;
+    int64_t queued = 0;
+    for (;;) {
+        a.max_iters = launch_iters;
+        if (max_steps >= 0) {
+            if (queued >= max_steps) break;
+            a.max_iters = (int)std::min<int64_t>(launch_iters, max_steps - queued);
+        }
+        queued += a.max_iters;
+        TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
+        hipError_t e = hipSuccess;
+        TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
+        if (e != hipSuccess) { tsp::set_last_error("k_cluster_two_opt launch", e, __FILE__, __LINE__); return TSP_DEV_E_HIP; }
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)B, hipMemcpyDeviceToHost, s));
+        int err = 0;
+        TSP_HIP_TRY(hipMemcpyAsync(&err, a.err, sizeof(int), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        if (err) {
+            tsp::set_last_error("k_cluster_two_opt: a workgroup of the cluster was not resident (exchange gave up)",
+                                hipErrorLaunchFailure, __FILE__, __LINE__);
+            if (fell_through) *fell_through = 1;
+            return TSP_DEV_E_HIP;
+        }
+        bool done = true;
+        for (int b = 0; b < B; ++b) done = done && t->h_state[b].done;
+        if (done) { if (all_done) *all_done = 1; break; }
+        if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
+    }
+    bool unfinished = status == TSP_TIME_LIMIT_EXCEEDED;
+    for (int b = 0; b < B; ++b) unfinished = unfinished || !t->h_state[b].done;
+    const int rc = tsp_grid_after_external_run(t, mode, unfinished);
+    return rc ? rc : status;
+}

@@ -218,6 +218,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     int64_t burst = sync ? 8 : batch;
     int64_t queued = 0;
     int status = TSP_OK;
+    bool finished = false;
     if (all_done) *all_done = 0;
     launch_arm(t, mode);
     for (;;) {
@@ -256,7 +257,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         TSP_HIP_TRY(hipStreamSynchronize(s));
         bool done = true;
         for (int b = 0; b < t->B; ++b) done = done && t->h_state[b].done;
-        if (done) { if (all_done) *all_done = 1; break; }
+        if (done) { finished = true; if (all_done) *all_done = 1; break; }
         if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
     }
     if ((mode == TSP_2OPT_BEST && !tabu && sorted_sweep(t)) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
@@ -264,8 +265,8 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         TSP_HIP_TRY(hipGetLastError());
         if (sync) TSP_HIP_TRY(hipStreamSynchronize(s));
     }
-    if (status == TSP_TIME_LIMIT_EXCEEDED && mode == TSP_2OPT_BEST) {
-        // the reference recomputes the cost on every exit path (tabusearch.c:168-172)
+    if ((status == TSP_TIME_LIMIT_EXCEEDED || (sync && !finished)) && mode == TSP_2OPT_BEST) {
+        // the reference recomputes the cost on every exit path (tabusearch.c:168-172); a run capped by max_steps too
         launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
         TSP_HIP_TRY(hipStreamSynchronize(s));
     }
@@ -396,6 +397,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_state_base); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
     (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
+    (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
     delete t;

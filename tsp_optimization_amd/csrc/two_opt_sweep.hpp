@@ -284,7 +284,10 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (ok[u]) {
-                            const double delta = pair_delta<WT, INT>(ri[u], rj);
+                            // the reference evaluates with the lower node id as `a` (tabusearch.c:128-150, i < j); with
+                            // non-integer costs the other operand order can differ by an ulp and flip a tie
+                            const double delta = (INT || ri[u].id < rj.id) ? pair_delta<WT, INT>(ri[u], rj)
+                                                                            : pair_delta<WT, INT>(rj, ri[u]);
                             const u64 kk = make_key(min(ri[u].id, rj.id), max(ri[u].id, rj.id));
                             if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) { bd = delta; key = kk; bound = bd; }
                         }

@@ -10,7 +10,7 @@ from .build import lib_path
 EUC_2D, MAX_2D, MAN_2D, CEIL_2D, GEO, ATT = 0, 1, 2, 3, 4, 5
 FIRST, BEST = 0, 1
 GREEDY, GRASP = 0, 1
-ENGINE_AUTO, ENGINE_GRID, ENGINE_LDS = 0, 1, 2
+ENGINE_AUTO, ENGINE_GRID, ENGINE_LDS, ENGINE_CLUSTER = 0, 1, 2, 3
 OK, WRONG_STARTING_NODE, TIME_LIMIT_EXCEEDED = 0, 1, 2
 
 
@@ -74,6 +74,7 @@ def lib():
         L.tsp_dev_tours_reset.argtypes = [vp]
         L.tsp_dev_tours_download.argtypes = [vp, ip, C.c_int, C.c_int64, dp, sp]
         L.tsp_dev_tours_run.argtypes = [vp, C.c_int, C.c_int64, C.c_double, C.c_int, ip]
+        L.tsp_dev_tours_run_engine.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_double, ip]
         L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
         _lib = L
@@ -87,7 +88,7 @@ EXPORTED = [
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
-    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
+    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
 ]
 
 
@@ -302,6 +303,13 @@ class Tours:
         """-> (status, all_done)"""
         done = C.c_int(0)
         rc = lib().tsp_dev_tours_run(self._h, mode, max_steps, time_limit, 1 if sync else 0, C.byref(done))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, bool(done.value)
+
+    def run_engine(self, mode, engine=ENGINE_AUTO, max_steps=-1, time_limit=-1.0):
+        """Resident tours on a chosen engine, waits for completion.  -> (status, all_done)"""
+        done = C.c_int(0)
+        rc = lib().tsp_dev_tours_run_engine(self._h, mode, engine, max_steps, time_limit, C.byref(done))
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
         return rc, bool(done.value)
 
