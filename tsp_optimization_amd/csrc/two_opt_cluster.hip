@@ -34,13 +34,24 @@ namespace tsp {
 constexpr int kClThreads = 512;
 constexpr int kClWaves = kClThreads / 64;
 constexpr int kClRows = 32;        // rows of one tile
-constexpr int kClListCap = 1024;   // surviving group pairs a workgroup holds at a time
-constexpr int kClUnitRows = 16;    // rows of one unit of wave work in the sorted scan
+constexpr int kClListCap = kClThreads;   // surviving group pairs a workgroup holds at a time (one round of box tests at least)
+
+constexpr int kClQueue = 128;      // per-wave ring of pairs waiting for tiers 1 and 2 (entries; a power of two >= 128)
 constexpr int kClSlotGranules = 4; // granules per workgroup and parity in the exchange area
 constexpr unsigned kClSpinLimit = 1u << 20;   // sweeps of the exchange area before a workgroup gives up (~ seconds)
 using idx_t = unsigned short;
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 using gi32c = __attribute__((address_space(1))) int;
+
+// Diagnostic build only (-DTSP_STAMPS): 100 MHz wall-clock time per phase, summed over a run by thread 0 of every
+// workgroup of tour 0, in a buffer nothing else reads (cdna_hip_programming.md section 7, in-kernel stamps).
+#ifdef TSP_STAMPS
+__device__ unsigned long long g_cl_prof[256][8];
+__device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: units, live rows, row quads, tier-1 blocks, tier-2 pairs, survivors
+#define CL_T(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define CL_T(k) do { } while (0)
+#endif
 
 struct ClusterArgs {
     const double2 *coord;   // internal numbering: node order (tiles) or Hilbert rank order incl. padding (sorted)
@@ -53,6 +64,7 @@ struct ClusterArgs {
     unsigned long long *slots;   // B x 2 x C x kClSlotGranules
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, count_evals;
+    int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
     double org_x, org_y;    // float replicas hold coordinates relative to this corner (exact: bounded integers)
     double margin, prune, sum_margin;
@@ -73,24 +85,63 @@ template <> struct ClCoord<float2> {
     }
 };
 
+// Staged node records of the sorted scan.  Integer-coordinate instances (float replica): every field is a bounded
+// integer, exact in a float, 24 bytes; otherwise the 48-byte NodeRec as it is.
+struct alignas(8) StageRecF {
+    float x, y, xs, ys, ds;
+    unsigned short succ, id;   // 0xffff = none (padding)
+};
+static_assert(sizeof(StageRecF) == 24, "StageRecF must be 24 bytes");
+template <typename CT> struct ClStage;
+template <> struct ClStage<float2> {
+    using rec = StageRecF;
+    static constexpr bool kF32 = true;
+    static __device__ __forceinline__ rec pack(const NodeRec &r) {
+        rec o;
+        o.x = (float)r.x; o.y = (float)r.y; o.xs = (float)r.xs; o.ys = (float)r.ys; o.ds = (float)r.ds;
+        o.succ = (unsigned short)r.succ; o.id = (unsigned short)r.id;   // -1 -> 0xffff
+        return o;
+    }
+    static __device__ __forceinline__ NodeRec unpack(const rec &o) {
+        NodeRec r;
+        r.x = (double)o.x; r.y = (double)o.y; r.xs = (double)o.xs; r.ys = (double)o.ys; r.ds = (double)o.ds;
+        r.succ = o.succ == 0xffffu ? -1 : (int)o.succ; r.id = o.id == 0xffffu ? -1 : (int)o.id;
+        return r;
+    }
+    static __device__ __forceinline__ void xyd(const rec &o, double &x, double &y, double &d) { x = (double)o.x; y = (double)o.y; d = (double)o.ds; }
+    static __device__ __forceinline__ void xydf(const rec &o, float &x, float &y, float &d) { x = o.x; y = o.y; d = o.ds; }
+};
+template <> struct ClStage<double2> {
+    using rec = NodeRec;
+    static constexpr bool kF32 = false;
+    static __device__ __forceinline__ rec pack(const NodeRec &r) { return r; }
+    static __device__ __forceinline__ NodeRec unpack(const rec &o) { return o; }
+    static __device__ __forceinline__ void xyd(const rec &o, double &x, double &y, double &d) { x = o.x; y = o.y; d = o.ds; }
+    static __device__ __forceinline__ void xydf(const rec &o, float &x, float &y, float &d) { x = (float)o.x; y = (float)o.y; d = (float)o.ds; }
+};
+
 __host__ __device__ inline size_t cl_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // LDS carve-up (host and device agree through this one function)
 struct ClLayout {
-    size_t coord, order, pos, gbox, gmax, urows, list, rows, scratch, total;
+    size_t coord, order, pos, gbox, gmax, stage, list, items, queue, rows, scratch, total;
 };
-__host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted) {
+constexpr int kClMaxStagePairs = 8;
+__host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted, int stage_pairs) {
     ClLayout L;
     size_t o = 0;
     L.coord = o; o = cl_align16(o + coord_elem * (size_t)nid);
     L.order = o; o = cl_align16(o + sizeof(idx_t) * (size_t)n);
     L.pos = o; o = cl_align16(o + sizeof(idx_t) * (size_t)nid);
-    L.gbox = L.gmax = L.urows = L.list = L.rows = o;
+    L.gbox = L.gmax = L.stage = L.list = L.items = L.queue = L.rows = o;
     if (sorted) {
+        const size_t rec = coord_elem == sizeof(float2) ? sizeof(StageRecF) : sizeof(NodeRec);
         L.gbox = o; o = cl_align16(o + sizeof(double4) * (size_t)ng);
         L.gmax = o; o = cl_align16(o + sizeof(double) * (size_t)ng);
-        L.urows = o; o = cl_align16(o + sizeof(NodeRec) * kClUnitRows * kClWaves);
+        L.stage = o; o = cl_align16(o + rec * 128 * (size_t)stage_pairs);
         L.list = o; o = cl_align16(o + sizeof(int) * kClListCap);
+        L.items = o; o = cl_align16(o + sizeof(unsigned short) * 64 * (size_t)stage_pairs);
+        L.queue = o; o = cl_align16(o + sizeof(unsigned) * kClQueue * kClWaves);
     } else {
         L.rows = o; o = cl_align16(o + sizeof(NodeRec) * kClRows);
     }
@@ -118,11 +169,6 @@ __device__ __forceinline__ double cl_dist(const CT *coord, int u, int v) {
     return dist_xy<WT, INT>((double)a.x, (double)a.y, (double)b.x, (double)b.y);
 }
 
-__device__ __forceinline__ double cl_lane_bcast(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // max over the 64 lanes of a non-negative double (orders like its bits)
 __device__ __forceinline__ double cl_wave_max_nonneg(double v) {
     const u64 mb = ~wave_min_u64(~(u64)__double_as_longlong(v));
@@ -138,39 +184,52 @@ struct ClCand {
 };
 
 // ---- the exchange: one candidate per workgroup and step -------------------------------------------------------
-// Producer: lane 0 of the workgroup, four 8-byte sc1 stores {epoch, payload} into the workgroup's slot of the
-// step's parity.  Consumer: wave 0 of every workgroup sweeps all C slots with sc1 loads until every tag carries the
-// epoch.  Two parities: a workgroup can be at most one step ahead of the slowest one (it cannot finish step s + 1
-// before everybody has published s + 1, i.e. has finished reading s), so slot parity s is never rewritten while
-// somebody still reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
-template <bool BEST>
+// Producer: lane 0 of the workgroup's first wave, NG 8-byte sc1 stores {epoch, payload}.  Consumer: the first wave of
+// every workgroup sweeps all C candidates with sc1 loads until every tag carries the epoch.  The area is laid out
+// granule-major ([parity][granule][workgroup]): one wave-instruction of the sweep reads 64 consecutive granules = four
+// whole 128-byte lines, and a candidate is as few granules as the variant allows --
+//   granule 0  the pair in the caller's numbering (two 16-bit ids; 0xffffffff = no candidate)
+//   granule 1  the pair in internal numbering (sorted scan only: elsewhere it is granule 0)
+//   then       the delta: one granule holding it as an int32 when the metric's values are bounded integers (SMALLD:
+//              the integer-coordinate variants, |delta| < 2^23), else two granules with the halves of the double.
+// Two parities: a workgroup can be at most one step ahead of the slowest one (it cannot finish step s + 1 before
+// everybody has published s + 1, i.e. has finished reading s), so parity s is never rewritten while somebody still
+// reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
+template <bool BEST, bool SORTED, bool SMALLD>
 __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err) {
+    constexpr int NG = 1 + (SORTED ? 1 : 0) + (SMALLD ? 1 : 2);
+    constexpr int GD = SORTED ? 2 : 1;   // first delta granule
     const int lane = threadIdx.x & 63;
     const u64 tag = (u64)ep << 32;
     gu64 *par = area + (size_t)(ep & 1u) * C * kClSlotGranules;
     if (lane == 0) {
-        gu64 *my = par + (size_t)c * kClSlotGranules;
         const u64 db = (u64)__double_as_longlong(cd.d);
         const unsigned kp = cd.key == kNoKey ? 0xffffffffu : (((unsigned)key_i(cd.key) & 0xffffu) << 16) | ((unsigned)key_j(cd.key) & 0xffffu);
-        __hip_atomic_store(my + 0, tag | kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(my + 1, tag | cd.ipair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(my + 2, tag | (db & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(my + 3, tag | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(par + c, tag | kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SORTED) __hip_atomic_store(par + C + c, tag | cd.ipair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SMALLD) {
+            __hip_atomic_store(par + GD * C + c, tag | (u64)(unsigned)(int)cd.d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(par + GD * C + c, tag | (db & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(par + (GD + 1) * C + c, tag | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    constexpr int Q = 4;   // C <= 256: at most four slots per lane
-    u64 g[Q][kClSlotGranules];
+    constexpr int Q = 4;   // C <= 256: at most four candidates per lane
+    u64 g[Q][NG];
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int k = q * 64 + lane;
-            if (k < C) {
+            if (q * 64 < C) {   // wave-uniform
+                if (k < C) {
 #pragma unroll
-                for (int w = 0; w < kClSlotGranules; ++w)
-                    g[q][w] = __hip_atomic_load(par + (size_t)k * kClSlotGranules + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int w = 0; w < NG; ++w)
+                        g[q][w] = __hip_atomic_load(par + (size_t)w * C + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-                for (int w = 0; w < kClSlotGranules; ++w) ok = ok && (g[q][w] >> 32) == (u64)ep;
+                    for (int w = 0; w < NG; ++w) ok = ok && (g[q][w] >> 32) == (u64)ep;
+                }
             }
         }
         if (__all(ok)) break;
@@ -191,9 +250,11 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
             const unsigned kp = (unsigned)g[q][0];
             if (kp != 0xffffffffu) {
                 const u64 kk = make_key((int)(kp >> 16), (int)(kp & 0xffffu));
-                const double d = __longlong_as_double((long long)((g[q][2] & 0xffffffffull) | (g[q][3] << 32)));
+                double d;
+                if constexpr (SMALLD) d = (double)(int)(unsigned)g[q][GD];
+                else d = __longlong_as_double((long long)((g[q][GD] & 0xffffffffull) | (g[q][GD + 1] << 32)));
                 const bool take = BEST ? better(d, kk, bd, key) : (kk < key);
-                if (key == kNoKey || take) { bd = d; key = kk; ip = (unsigned)g[q][1]; }
+                if (key == kNoKey || take) { bd = d; key = kk; ip = SORTED ? (unsigned)g[q][1] : kp; }
             }
         }
     }
@@ -213,17 +274,22 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     static_assert(!SORTED || (MODE == TSP_2OPT_BEST && has_root_filter<WT>()), "the sorted scan is a best-improvement sweep on a sqrt metric");
     constexpr bool BEST = MODE == TSP_2OPT_BEST;
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
+    // bounded integer distances (< 2^21): a delta is an integer below 2^23 in magnitude and travels as an int32
+    constexpr bool kSmallD = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = a.n, nid = a.nid, ng = a.ng, C = a.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tour = (int)blockIdx.x / C, c = (int)blockIdx.x % C;
-    const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED);
+    using SR = ClStage<CT>;
+    const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED, a.stage_pairs);
     CT *coord = reinterpret_cast<CT *>(smem + L.coord);
     idx_t *order = reinterpret_cast<idx_t *>(smem + L.order);
     idx_t *pos = reinterpret_cast<idx_t *>(smem + L.pos);
     double4 *gbox = reinterpret_cast<double4 *>(smem + L.gbox);
     double *gmax = reinterpret_cast<double *>(smem + L.gmax);
-    NodeRec *s_urows = reinterpret_cast<NodeRec *>(smem + L.urows);
+    typename SR::rec *stage = reinterpret_cast<typename SR::rec *>(smem + L.stage);
+    unsigned short *s_items = reinterpret_cast<unsigned short *>(smem + L.items);
+    unsigned *s_queue = reinterpret_cast<unsigned *>(smem + L.queue);
     int *s_list = reinterpret_cast<int *>(smem + L.list);
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem + L.rows);
     char *scratch = smem + L.scratch;
@@ -235,7 +301,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     u64 *s_win_k = reinterpret_cast<u64 *>(scratch + 456);
     unsigned *s_win_ip = reinterpret_cast<unsigned *>(scratch + 464);
     int *s_fail = reinterpret_cast<int *>(scratch + 468);
-    unsigned *s_blk_ip = reinterpret_cast<unsigned *>(scratch + 472);   // the workgroup's own winner (before the exchange)
+    static_assert(kClWaves <= 8, "scratch carve-up: eight wave winners");
+    unsigned *s_ip = reinterpret_cast<unsigned *>(scratch + 480);      // 8: the waves' winners (internal pairs)
+    int *s_nitems = reinterpret_cast<int *>(scratch + 476);   // the workgroup's own winner (before the exchange)
     double *s_chunk = reinterpret_cast<double *>(scratch + 512);       // 64 doubles (fcost cost recompute)
 
     TourState *st = a.states + tour;
@@ -281,6 +349,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 
     const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
     bool failed = false;
+#ifdef TSP_STAMPS
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#endif
     for (int iter = 0; iter < a.max_iters && !done; ++iter) {
         int row_lo = 0, row_hi = n - 1;
         if constexpr (!BEST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
@@ -291,6 +362,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         if constexpr (SORTED) {
             // ---- sorted scan: box tests on this workgroup's share of the group pairs, then the survivors ------
             const int *tab = a.pairtab + (size_t)c * a.ntests;
+            const int P = a.stage_pairs;
             int m0 = 0;
             while (m0 < a.ntests) {
                 int kept = 0;
@@ -317,110 +389,175 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     m0 += kClThreads;
                     __syncthreads();
                 }
-                // units of 16 rows x 64 columns, dealt to the waves in turn; the waves share nothing until the arg-min
-                constexpr int UPP = 64 / kClUnitRows;
-                NodeRec *rows = s_urows + wave * kClUnitRows;
-                for (int u = wave; u < UPP * kept; u += kClWaves) {
-                    const int e = s_list[u / UPP];
-                    const int r = e >> 16, cgp = e & 0xffff, row0 = (u % UPP) * kClUnitRows;
-                    const int cslot = cgp * 64 + lane, rslot = r * 64 + row0 + (lane & (kClUnitRows - 1));
-                    NodeRec rj, rr;
-                    rj.x = rj.y = rj.xs = rj.ys = 1e30; rj.ds = 0.0; rj.succ = -1; rj.id = -1;   // padding: far from everything
-                    rr = rj;
-                    if (cslot < n) rj = cl_node<WT, INT, CT>(coord, order, pos, n, cslot);
-                    if (rslot < n) rr = cl_node<WT, INT, CT>(coord, order, pos, n, rslot);
-                    if (lane < kClUnitRows) rows[lane] = rr;   // tiers 1 and 2 read whole row records (same wave: LDS keeps order)
-                    const double cds = rj.ds + prune2, cds2 = rj.ds + a.sum_margin;
-                    double bound = bd;   // the lane's own best so far
-                    // rows that cannot reach the column group's box at all are dropped for the whole wave
-                    unsigned alive;
-                    const double hx = rr.x, hy = rr.y, hd = rr.ds;
-                    {
-                        const double4 cb = gbox[cgp];
-                        const double cmax = cl_wave_max_nonneg(rj.ds);   // longest edge leaving one of these columns
-                        const double gx = fmax(0.0, fmax(cb.x - rr.x, rr.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rr.y, rr.y - cb.w));
-                        const double T = rr.ds + cmax + prune2;
-                        const bool reach = lane < kClUnitRows && ((a.dbg & 2) || gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T));
-                        alive = __builtin_amdgcn_readfirstlane((unsigned)__ballot(reach));
-                    }
-                    auto rare4 = [&](const int (&idx)[4], const bool (&need)[4]) {
-                        // tier 1, both new edges, no root: |ab| + |a1 b1| < T2 = bound + d(a,a1) + d(b,b1) + margin
-                        //   <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2
-                        bool ok[4];
-                        bool any2 = false;
-                        NodeRec ri[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ri[q] = rows[idx[q]];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const double dx1 = ri[q].x - rj.x, dy1 = ri[q].y - rj.y;
-                            const double dx = ri[q].xs - rj.xs, dy = ri[q].ys - rj.ys, T2 = ri[q].ds + bound + cds2;
-                            const double sc = ATT10 ? 0.1 : 1.0;
-                            const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
-                            const double w = T2 * T2 - p1 - p2;
-                            ok[q] = need[q] & (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
-                                    ((cgp > r) | (row0 + idx[q] < lane)) & (ri[q].id >= 0) & (rj.id >= 0) &
-                                    (rj.id != ri[q].succ) & (rj.succ != ri[q].id);
-                            any2 = any2 | ok[q];
+                CL_T(0);
+                // The survivors, P group pairs at a time.  Work is dealt in three grains, because a step costs the time of its
+                // slowest wave and the pairs that reach the expensive tiers are concentrated in a few group pairs (a group
+                // against itself or its neighbours):
+                //  (1) stage: the records of both groups of every pair are derived once, one record per thread and round
+                //      (slot 2 pe = the row group, 2 pe + 1 = the column group).  A row-side thread also culls its row -- a
+                //      row that cannot reach the column group's box is dropped -- and the live rows go into one list;
+                //  (2) live rows, four at a time per wave and turn (the 64 rows of a heavy pair end up on all waves): tier 0
+                //      against the 64 columns; the pairs that survive it are queued per wave;
+                //  (3) queued pairs, 64 at a time (one per lane): tiers 1 and 2 run on full waves, not on the few lanes of
+                //      a row that happen to need them.
+                for (int e0 = 0; e0 < kept; e0 += P) {
+                    const int ne = min(P, kept - e0);
+                    if (tid == 0) *s_nitems = 0;
+                    __syncthreads();
+                    for (int x = tid; x < ne * 128; x += kClThreads) {   // whole waves: ne * 128 is a multiple of 64
+                        const int pe = x >> 7;
+                        const int e = s_list[e0 + pe];
+                        const bool row_side = ((x >> 6) & 1) == 0;
+                        const int cgp = e & 0xffff;
+                        const int g = row_side ? (e >> 16) : cgp;
+                        const int v = g * 64 + (x & 63);
+                        NodeRec rec;
+                        rec.x = rec.y = rec.xs = rec.ys = 1e30; rec.ds = 0.0; rec.succ = -1; rec.id = -1;   // padding: far from everything
+                        if (v < n) rec = cl_node<WT, INT, CT>(coord, order, pos, n, v);
+                        stage[x] = SR::pack(rec);
+                        if (row_side) {   // wave-uniform
+                            const double4 cb = gbox[cgp];
+                            const double gx = fmax(0.0, fmax(cb.x - rec.x, rec.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rec.y, rec.y - cb.w));
+                            const double T = rec.ds + gmax[cgp] + prune2;
+                            const bool reach = (a.dbg & 2) ? v < n : gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+                            const unsigned long long m = __ballot(reach);
+                            if (m) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(s_nitems, __popcll(m));
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (reach) s_items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)x;
+                            }
                         }
-                        if (any2) {   // tier 2: the exact delta, lower node id first (tabusearch.c:150 with i < j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (ok[q]) {
+                    }
+                    __syncthreads();
+                    CL_T(8);
+                    {
+                        const int nit = *s_nitems;
+#ifdef TSP_STAMPS
+                        if (tid == 0) prof[11] += nit;
+#endif
+                        unsigned *q = s_queue + wave * kClQueue;
+                        int qhead = 0, qtail = 0;   // wave-uniform
+                        // tiers 1 and 2 for `cnt` queued pairs, one per lane
+                        auto dense = [&](int cnt) {
+                            if (lane < cnt) {
+                                const unsigned en = q[(qhead + lane) & (kClQueue - 1)];
+                                const NodeRec ri = SR::unpack(stage[en & 0xffffu]), rj = SR::unpack(stage[en >> 16]);
+                                // tier 1, both new edges, no root: |ab| + |a1 b1| < T2 = bound + d(a,a1) + d(b,b1) + margin
+                                //   <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2   (bound: this lane's best so far)
+                                const double dx1 = ri.x - rj.x, dy1 = ri.y - rj.y;
+                                const double dx = ri.xs - rj.xs, dy = ri.ys - rj.ys, T2 = ri.ds + bd + rj.ds + a.sum_margin;
+                                const double sc = ATT10 ? 0.1 : 1.0;
+                                const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
+                                const double w = T2 * T2 - p1 - p2;
+                                const bool ok = (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
+                                                (rj.id != ri.succ) & (rj.succ != ri.id);   // never adjacent nodes
+                                if (ok) {   // tier 2: the exact delta, lower node id first (tabusearch.c:150 with i < j)
                                     int gi = 0, gj = 0;
                                     double delta;
                                     if constexpr (INT) {
-                                        delta = pair_delta<WT, INT>(ri[q], rj);   // integer-valued terms: the sum is exact in any order
+                                        delta = pair_delta<WT, INT>(ri, rj);   // integer-valued terms: the sum is exact in any order
                                     } else {
-                                        gi = a.gid[ri[q].id]; gj = a.gid[rj.id];
-                                        delta = gi < gj ? pair_delta<WT, INT>(ri[q], rj) : pair_delta<WT, INT>(rj, ri[q]);
+                                        gi = a.gid[ri.id]; gj = a.gid[rj.id];
+                                        delta = gi < gj ? pair_delta<WT, INT>(ri, rj) : pair_delta<WT, INT>(rj, ri);
                                     }
                                     if (delta < bd || (delta == bd && delta < 0.0)) {
-                                        if constexpr (INT) { gi = a.gid[ri[q].id]; gj = a.gid[rj.id]; }
+                                        if constexpr (INT) { if (a.dbg & 8) { gi = ri.id; gj = rj.id; } else { gi = a.gid[ri.id]; gj = a.gid[rj.id]; } }
                                         const u64 kk = make_key(min(gi, gj), max(gi, gj));
                                         if (delta < bd || kk < key) {
-                                            bd = delta; key = kk; bound = bd;
-                                            ipair = gi < gj ? (((unsigned)ri[q].id << 16) | (unsigned)rj.id)
-                                                            : (((unsigned)rj.id << 16) | (unsigned)ri[q].id);
+                                            bd = delta; key = kk;
+                                            ipair = gi < gj ? (((unsigned)ri.id << 16) | (unsigned)rj.id)
+                                                            : (((unsigned)rj.id << 16) | (unsigned)ri.id);
                                         }
                                     }
                                 }
                             }
-                        }
-                    };
-                    while (alive) {
-                        int idx[4];
+                            qhead += cnt;
+#ifdef TSP_STAMPS
+                            if (tid == 0) { prof[6] += 1; prof[7] += cnt; }
+#endif
+                        };
+                        constexpr int RU = 4;   // rows in flight per wave: their LDS reads are issued together
+                        for (int k0 = wave * RU; k0 < nit; k0 += kClWaves * RU) {
+                            int ridx[RU], cidx[RU], ee[RU];
+                            bool valid[RU], need[RU];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (alive) { idx[q] = __builtin_ctz(alive); alive &= alive - 1; }
-                            else idx[q] = idx[q > 0 ? q - 1 : 0];
-                        }
-                        bool need[4];
-                        bool any = false;
+                            for (int qq = 0; qq < RU; ++qq) {
+                                valid[qq] = k0 + qq < nit;
+                                ridx[qq] = (int)s_items[min(k0 + qq, nit - 1)];
+                            }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin
-                            const double rx = cl_lane_bcast(hx, idx[q]), ry = cl_lane_bcast(hy, idx[q]), rd = cl_lane_bcast(hd, idx[q]);
-                            const double dx = rx - rj.x, dy = ry - rj.y, T = rd + bound + cds;
-                            need[q] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);   // T <= 0: never
-                            any = any || need[q];
+                            for (int qq = 0; qq < RU; ++qq) {
+                                const int pe = ridx[qq] >> 7;
+                                ee[qq] = s_list[e0 + pe];
+                                cidx[qq] = (2 * pe + 1) * 64 + lane;
+                            }
+                            // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin; the row's x, y and edge
+                            // length are a wave-uniform LDS read (broadcast), the column's one read per lane
+                            if constexpr (SR::kF32) {
+                                // integer coordinates (exact as floats): a float test with its rounding paid for in slack -- s may
+                                // come out low by 2^-22 relative, T (< 2^23) is taken 2 units high; half the issue cost of fp64
+                                float rx[RU], ry[RU], rd[RU], cxf[RU], cyf[RU], cdf[RU];
+#pragma unroll
+                                for (int qq = 0; qq < RU; ++qq) {
+                                    SR::xydf(stage[ridx[qq]], rx[qq], ry[qq], rd[qq]);
+                                    SR::xydf(stage[cidx[qq]], cxf[qq], cyf[qq], cdf[qq]);
+                                }
+                                const float bf = (float)(bd + prune2 + 2.0);
+#pragma unroll
+                                for (int qq = 0; qq < RU; ++qq) {
+                                    const float dx = rx[qq] - cxf[qq], dy = ry[qq] - cyf[qq], T = rd[qq] + cdf[qq] + bf;
+                                    need[qq] = fmaf(dx, dx, dy * dy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
+                                }
+                            } else {
+                                double rx[RU], ry[RU], rd[RU], cx[RU], cy[RU], cd[RU];
+#pragma unroll
+                                for (int qq = 0; qq < RU; ++qq) {
+                                    SR::xyd(stage[ridx[qq]], rx[qq], ry[qq], rd[qq]);
+                                    SR::xyd(stage[cidx[qq]], cx[qq], cy[qq], cd[qq]);
+                                }
+#pragma unroll
+                                for (int qq = 0; qq < RU; ++qq) {
+                                    const double dx = rx[qq] - cx[qq], dy = ry[qq] - cy[qq], T = rd[qq] + cd[qq] + bd + prune2;
+                                    need[qq] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);
+                                }
+                            }
+#pragma unroll
+                            for (int qq = 0; qq < RU; ++qq) {
+                                // one slot pair once (inside a group: row slot below column slot); padding columns never
+                                const int r = ee[qq] >> 16, cgp = ee[qq] & 0xffff;
+                                const bool nd = need[qq] & valid[qq] & (cgp * 64 + lane < n) & ((cgp > r) | ((ridx[qq] & 63) < lane));
+                                const unsigned long long m = __ballot(nd);
+                                if (m) {
+                                    if (nd) q[(qtail + __popcll(m & ((1ull << lane) - 1ull))) & (kClQueue - 1)] = (unsigned)ridx[qq] | ((unsigned)cidx[qq] << 16);
+                                    qtail += __popcll(m);
+                                    if (qtail - qhead >= 64) dense(64);
+                                }
+                            }
                         }
-                        if (any) rare4(idx, need);
+                        if (qtail > qhead) dense(qtail - qhead);
                     }
+                    CL_T(10);
+                    __syncthreads();   // the stage (and, after the last chunk, the list) is rewritten next
                 }
-                __syncthreads();   // the list is rewritten by the next pass
             }
         } else {
-            // ---- tiles: 32 rows x 512 columns, tile t = row block * nb + column batch, dealt round-robin ---------
+            // ---- tiles: rpt rows x 512 columns, tile t = row block * nb + column batch, dealt round-robin.  A step costs
+            // the latency of its slowest workgroup, so the rows per tile shrink until every workgroup of the cluster has a
+            // tile (a first-improvement step right after a move scans a few dozen rows: 20 tiles of 32 rows would leave
+            // 236 of 256 workgroups idle and make the 20 busy ones eight times slower than they need be)
             const int nb = (n + kClThreads - 1) / kClThreads;
-            const int nrb = (row_hi - row_lo + kClRows - 1) / kClRows;
+            const int nrows = row_hi - row_lo;
+            const int rbs = C / nb;   // row blocks that give every workgroup at most one tile
+            const int rpt = rbs > 0 ? max(1, min(kClRows, (nrows + rbs - 1) / rbs)) : kClRows;
+            const int nrb = (nrows + rpt - 1) / rpt;
             int hit_rb = nrb;   // FIRST: first row block in which this workgroup has found an improving pair
             bool any_hit = false;
             for (int t = c; t < nrb * nb; t += C) {
                 const int rbi = t / nb, b = t - rbi * nb;
                 if (!BEST && rbi > hit_rb) break;   // later rows only hold later pairs
-                const int rb = row_lo + rbi * kClRows;
-                const int nr = min(kClRows, row_hi - rb);
+                const int rb = row_lo + rbi * rpt;
+                const int nr = min(rpt, row_hi - rb);
                 const int j = b * kClThreads + tid;
                 // no column of this batch above the first row (or, in the cursor's row alone, above the cursor)
                 const int jmin = (!BEST && nr == 1 && rb == ci) ? max(rb, cj) : rb;
@@ -464,28 +601,39 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
         }
 
+        CL_T(1);
         // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
+        // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
+        // winners through LDS to the first wave, which reduces them, runs the exchange and hands the result back
         {
+            if constexpr (!SORTED) { if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key); }
             const u64 mykey = key;
-            block_argmin<BEST>(bd, key, s_d, s_k);
-            if constexpr (SORTED) {
-                if (mykey == key && key != kNoKey) *s_blk_ip = ipair;   // exactly one thread evaluated the winning pair
-                __syncthreads();
-                if (key != kNoKey) ipair = *s_blk_ip;
-            } else if (key != kNoKey) {
-                ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
-            }
+            wave_argmin<BEST>(bd, key);
+            const unsigned long long owners = __ballot(mykey == key && key != kNoKey);
+            if (owners) ipair = (unsigned)__builtin_amdgcn_readlane((int)ipair, __builtin_ctzll(owners));
+            if (lane == 0) { s_d[wave] = bd; s_k[wave] = key; s_ip[wave] = ipair; }
         }
-        if (C > 1) {
-            if (wave == 0) {
-                ClCand cd{bd, key, ipair};
-                const bool okx = cl_exchange<BEST>(area, C, c, (unsigned)(iter + 1), cd, a.err);
-                if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
-            }
-            __syncthreads();
-            if (*s_fail) { failed = true; break; }
-            bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        __syncthreads();
+        CL_T(2);
+        if (wave == 0) {
+            double d = 0.0;
+            u64 k2 = kNoKey;
+            unsigned ip = 0;
+            if (lane < kClWaves) { d = s_d[lane]; k2 = s_k[lane]; ip = s_ip[lane]; }
+            const u64 mine = k2;
+            wave_argmin<BEST>(d, k2);
+            const unsigned long long owners = __ballot(mine == k2 && k2 != kNoKey);
+            unsigned wip = 0;
+            if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
+            ClCand cd{d, k2, wip};
+            bool okx = true;
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, (unsigned)(iter + 1), cd, a.err);
+            if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
         }
+        __syncthreads();
+        if (*s_fail) { failed = true; break; }
+        bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        CL_T(3);
         const bool found = key != kNoKey && (!BEST || bd < 0);
         const int wi = found ? (int)(ipair >> 16) : -1, wj = found ? (int)(ipair & 0xffffu) : -1;   // internal ids
 
@@ -508,6 +656,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             }
         }
 
+        CL_T(4);
         // ---- move: reverse positions pa+1 .. pb (cyclic), src/utility.c:708-717 ------------------------------------
         int Lr = 0;
         if (found) {
@@ -540,6 +689,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         }
         __syncthreads();
 
+        CL_T(5);
         // ---- control block ------------------------------------------------------------------------------------------
         steps += 1;
         if constexpr (BEST) {
@@ -591,6 +741,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         }
     }
 
+#ifdef TSP_STAMPS
+    if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][7] += steps - st->steps; }
+    if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
+#endif
     // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
     if (failed || c != 0) return;
     __syncthreads();
@@ -633,7 +787,7 @@ constexpr bool cl_float_coords() {
 struct ClPlan {
     bool ok = false, sorted = false, float_coords = false;
     size_t lds = 0;
-    int nid = 0;
+    int nid = 0, stage_pairs = 0;
 };
 
 // Which scan a run in `mode` uses on this handle, and whether the replica fits in LDS.
@@ -646,8 +800,13 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     p.sorted = mode == TSP_2OPT_BEST && inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
                inst->n >= t->sorted_min_n;
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
-    p.lds = cl_layout(inst->n, p.nid, inst->ng, p.float_coords ? sizeof(float2) : sizeof(double2), p.sorted).total;
-    p.ok = p.lds <= kLdsLimit;
+    const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
+    // as many staged group pairs as fit (at least one), at most kClMaxStagePairs
+    for (p.stage_pairs = p.sorted ? kClMaxStagePairs : 0;; --p.stage_pairs) {
+        p.lds = cl_layout(inst->n, p.nid, inst->ng, ce, p.sorted, p.stage_pairs).total;
+        p.ok = p.lds <= kLdsLimit;
+        if (p.ok || p.stage_pairs <= 1) break;
+    }
     return p;
 }
 
@@ -674,6 +833,22 @@ hipError_t cl_launch(tsp_dev_tours *t, int mode, const ClPlan &p, const ClusterA
 
 // implemented in two_opt_grid.hip
 int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+
+#ifdef TSP_STAMPS
+// diagnostic: per workgroup of tour 0, 100 MHz ticks per phase {tests, scan, block arg-min, exchange, counters, move, -, steps}; resets
+extern "C" int tsp_dev_debug_cluster(unsigned long long *out /* 256 x 8 */) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_prof), sizeof(unsigned long long) * 256 * 8) != hipSuccess) return -1;
+    static unsigned long long z[256 * 8];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_prof), z, sizeof z);
+    return 0;
+}
+extern "C" int tsp_dev_debug_cluster_counts(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_cl_cnt), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_cnt), z, sizeof z);
+    return 0;
+}
+#endif
 
 bool tsp_cluster_fits(const tsp_dev_tours *t, int mode) { return t && cl_plan(t, mode).ok; }
 bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode) { return t && cl_plan(t, mode).sorted; }
@@ -764,6 +939,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;
     a.dbg = env_int("TSP_CLUSTER_DEBUG", 0);
+    a.stage_pairs = p.stage_pairs;
     a.org_x = inst->org_x; a.org_y = inst->org_y;
     a.margin = inst->filter_margin; a.prune = inst->prune_margin; a.sum_margin = inst->sum_margin;
     // FIRST chunk geometry: a step costs a few microseconds whatever it scans, so the smallest chunk grows with the
