@@ -948,7 +948,9 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     const int auto_rmin = (int)std::max<long long>(1, std::min<long long>(64, (per_step + n / 2) / n));
     a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", auto_rmin)));
     a.rmax = std::max(a.rmin, std::min(2048, env_int("TSP_CLUSTER_MAX_ROWS", C == 1 ? kClRows : std::max(kClRows, 8 * C))));
-    const int launch_iters = mode == TSP_2OPT_FIRST ? 16384 : 4096;   // steps per launch (a time limit is honoured between launches)
+    // steps per launch: a time limit is honoured between launches (the reference checks it per sweep / per pair), so a
+    // limited run is cut into launches of a millisecond or two (a relaunch reloads the replicas: ~0.1 ms)
+    const int launch_iters = time_limit_s > 0 ? (mode == TSP_2OPT_FIRST ? 256 : 128) : (mode == TSP_2OPT_FIRST ? 16384 : 4096);
 
     const double t0 = wall_s();
     int status = TSP_OK;
