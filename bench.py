@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- 2-opt edge-pair evaluations per second on MI355X (BASELINE.json's metric).
+"""bench.py -- 2-opt edge-pair evaluations per second and time-to-local-optimum on MI355X (BASELINE.json's metric).
 
-Workload (BASELINE.json configs[2], the one the >=1e9 evals/s target is quoted on): synthetic random
-EUC_2D, n = 10000, numpy default_rng(10000) integer coordinates in [0,1e6)^2, integer costs.
-One *step* = one best-improvement sweep of alg_2opt_tabu (src/tabusearch.c:128-165): evaluate every
-non-adjacent (i<j) pair of the current tour (n(n-1)/2 - n = 49,985,000 delta evaluations), pick the
-arg-min, apply the move (segment reversal) -- continuing the descent from the nearest-neighbour
-tour, so every step is real work on a different tour.  Inputs are resident in HBM before the timed
-region.  With N GPUs each rank refines its own start (greedy from node = rank): weak scaling, no
-data-path collective; one RCCL all-reduce(min) of the packed (cost, rank) follows the timed region.
+Workload (BASELINE.json configs[2], the one the >= 1e9 evals/s target is quoted on): synthetic random EUC_2D,
+n = 10000, numpy default_rng(10000) integer coordinates in [0,1e6)^2, integer costs, single start.
 
-Also reported (rank 0, N = 1): time-to-local-optimum for both selection rules with the tour-cost
-match against the reference's known answer, the dominant kernel's roofline numbers, and a CPU
-baseline (the oracle, one core, bounded sample).
+One *step* = ONE FULL best-improvement 2-opt descent (alg_2opt_tabu with skip_edge == NULL, src/tabusearch.c:107-178)
+of the nearest-neighbour tour greedy(start = rank) to its local optimum: 1428 sweeps for rank 0, every sweep deciding
+all n(n-1)/2 - n = 49 985 000 non-adjacent pairs, picking the arg-min, reversing the segment.  The tour is resident in
+HBM (tsp_dev_tours) before the timed region starts; a step restores it device-to-device and runs the product's default
+engine for resident tours (TSP_ENGINE_AUTO -> CLUSTER: 256 workgroups, one descent = one launch).  The final tour is
+checked against the committed golden vector after the timed region.
+
+What the line reports, kept strictly apart:
+  value                               pair evaluations the device EXECUTED per second: pairs for which a lane
+                                      evaluated a lower bound of delta or delta itself (tier counters of the kernel);
+  evals.exact_delta_per_s             delta expressions (tabusearch.c:150) actually executed per second;
+  evals.reference_equivalent_pairs_per_s   pairs DECIDED per second (what the reference would have executed for the
+                                      same, bit-identical decisions) -- most are decided 64 x 64 at a time by a box bound;
+  roofline                            bound "valu": counted floating-point lane-operations of the executed tiers / kernel
+                                      time against the fp64 vector peak, frac <= 1; the same for the exhaustive tiled
+                                      sweep (every delta expression executed) in roofline.exhaustive.
+With N GPUs each rank refines its own start (weak scaling, no data-path collective); after the timed region the ranks
+run the sharded multi-start configs (BASELINE configs[3], [4]) with one RCCL all-reduce(min) + one broadcast each.
 """
 import argparse
 import json
@@ -26,91 +35,162 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_NODES = 10000
-ALGO_BYTES_PER_EVAL = 72.0     # 2 successor loads + 4 points x 16 B
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_LANE_OPS_PEAK = 39.3e12     # 78.6 TFLOP/s fp64 vector (FMA = 2 flops) = 39.3 T lane-instructions/s
+# counted floating-point lane-operations per unit of executed work (fp32 operations count 1/2)
+OPS_TIER0_F32 = 11 * 0.5         # dx, dy, dx*dx, fma, two adds for T, T*|T|, two scalings, compare
+OPS_TIER1 = 26.0                 # both new edges without a root: 4 sub, 3 add, 2 x (mul + fma + scale), w, 4 p1 p2, w^2, 3 compares
+OPS_EXACT = 35.0                 # 31 fp64 operations + 4 roots per delta expression
+OPS_STAGED = 24.0                # one node record: rounded root distance (12) + row culling against a box (12)
+OPS_BOXTEST = 14.0               # one group pair: box gap (6), bound (3), squares and compare (5)
 
 
 def rand_instance(n):
     return np.random.default_rng(n).integers(0, 1_000_000, size=(n, 2)).astype(np.float64)
 
 
-def other_configs(E, ctx, O):
-    """BASELINE configs[3] and [4] on this GPU (reported next to the headline; parity-checked inline)."""
+def fnv1a(v):
+    """The hash of a successor list the golden fixtures carry (FNV-1a walk over the bytes of the int32 array, with the
+    basis the fixture generator has used since round 1: 1469598103934665603)."""
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(v, dtype=np.int32).tobytes():
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def golden(name):
+    with open(os.path.join(ROOT, "tests", "golden", name)) as f:
+        return json.load(f)
+
+
+def sharded_configs(E, MS, ctx, rank, world, device):
+    """BASELINE configs[3] and [4] sharded k % world over the ranks: construct + 2-opt per rank, one all_reduce(MIN) of
+    the packed (cost, start), one broadcast of the winner's tour; every rank checks the winner against the goldens."""
     res = {}
+
+    def wall(seconds):
+        if world == 1:
+            return seconds
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # configs[3]: att532, 256 GRASP starts (seed 123, stream order of heuristics.c:519 then :127) + alg_2opt each
-    xy, wt = O.parse_tsplib(os.path.join(ROOT, "tests", "golden", "instances", "att532.tsp"))
+    from tsp_optimization_amd import tsplib
+    xy, wt = tsplib.parse(os.path.join(ROOT, "tests", "golden", "instances", "att532.tsp"))
     n = len(xy)
     inst = E.Instance(ctx, xy, wt, 1)
-    O.srandom(123)
-    B = 256
-    starts = np.zeros(B, dtype=np.int32)
-    urand = np.zeros((B, n))
-    for b in range(B):
-        starts[b] = int(O.urand() * (n - 1))
-        urand[b] = [O.urand() for _ in range(n)]
-    inst.two_opt(*inst.construct(E.GRASP, starts[:8], urand[:8])[:2], mode=E.FIRST)   # warm
+    rng = MS.LibcRandom(123)
+    starts, stream = MS.grasp_stream(rng.urand, n, 256)
+    refine = MS.config4_refiner(E, inst, starts, stream)
+    refine(MS.shard_starts(256, rank, world)[:4])   # warm
     t0 = time.perf_counter()
-    succ, obj, _ = inst.construct(E.GRASP, starts, urand)
-    t1 = time.perf_counter()
-    rc, s2, o2, st = inst.two_opt(succ, obj, mode=E.FIRST)
-    t2 = time.perf_counter()
-    true_cost = inst.perm_cost(np.stack([O.succ_to_perm(s) for s in s2]))
-    k = int(np.lexsort((np.arange(B), true_cost))[0])
-    with open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")) as f:
-        table = json.load(f)["att532_multistart256"]
+    out = MS.run_sharded(refine, 256, n, rank, world, device)
+    t_all = wall(time.perf_counter() - t0)
+    table = golden("oracle_vectors.json")["att532_multistart256"]
+    assert (out["cost"], out["start"]) == (28998, 122), out            # SURVEY.md 8(d): best true cost 28998 at start 122
+    assert fnv1a(out["tour"]) == table[122]["hash"], "winner's tour differs from the golden"
     res["config4_att532_grasp256_2opt"] = {
-        "construct_ms": 1e3 * (t1 - t0), "two_opt_ms": 1e3 * (t2 - t1), "best_true_cost": float(true_cost[k]),
-        "best_start": k, "reference_best": [28998, 122],
-        "all_256_tours_match_golden": bool(all(O.fnv1a(s2[i]) == table[i]["hash"] for i in range(B))),
-        "reference_equivalent_evals": int(sum(x["evals"] for x in st)),
-        "cpu_reference_s": 27.6, "cpu_reference_note": "SURVEY.md section 6, unmodified reference, one core"}
+        "starts": 256, "starts_per_rank": out["local_starts"], "wall_s": t_all, "refine_s_max_over_ranks": wall(out["seconds"]),
+        "best_true_cost": out["cost"], "best_start": out["start"], "winner_tour_matches_golden": True,
+        "collectives": "all_reduce(MIN) int64 + broadcast 4n bytes" if world > 1 else "none (1 GPU)"}
     inst.close()
-    # configs[4]: synthetic n=5000, 128 random individuals (genetic.c:349-364) each refined by alg_2opt
+
+    # configs[4]: synthetic n = 5000, 128 random individuals (genetic.c:349-364, seed 123) each refined by alg_2opt
     xy = rand_instance(5000)
     inst = E.Instance(ctx, xy, E.EUC_2D, 1)
-    O.srandom(123)
-    perms = np.stack([O.random_perm(5000) for _ in range(128)])
-    succ = np.stack([O.perm_to_succ(p) for p in perms])
+    rng = MS.LibcRandom(123)
+    perms = np.stack([rng.random_perm(5000) for _ in range(128)])
+    refine = MS.config5_refiner(E, inst, perms)
     t0 = time.perf_counter()
-    cost = inst.perm_cost(perms)
-    t1 = time.perf_counter()
-    rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST)
-    t2 = time.perf_counter()
-    ev = int(sum(x["evals"] for x in st))
+    out = MS.run_sharded(refine, 128, 5000, rank, world, device)
+    t_all = wall(time.perf_counter() - t0)
+    gold = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]["individuals"]
+    best = min(gold, key=lambda r: (r["cost"], r["k"]))
+    assert (out["cost"], out["start"]) == (int(best["cost"]), best["k"]), (out["cost"], out["start"], best)
+    assert fnv1a(out["tour"]) == best["hash"], "winner's tour differs from the golden"
+    mine = MS.shard_starts(128, rank, world)
+    ev = int(sum(x["evals"] for x in refine.stats))
+    assert all(int(refine.stats[i]["evals"]) == gold[k]["ev"] and int(refine.stats[i]["moves"]) == gold[k]["mv"]
+               for i, k in enumerate(mine)), "per-individual counters differ from the golden table"
     res["config5_rand5000_population128_2opt"] = {
-        "fitness_ms": 1e3 * (t1 - t0), "two_opt_s": t2 - t1, "reference_equivalent_evals": ev,
-        "reference_equivalent_evals_per_s": ev / (t2 - t1), "moves": int(sum(x["moves"] for x in st)),
-        "best_cost": float(o2.min()), "costs_equal_recomputed": bool((o2 == inst.perm_cost(np.stack([O.succ_to_perm(s) for s in s2]))).all())}
+        "individuals": 128, "individuals_per_rank": out["local_starts"], "wall_s": t_all,
+        "refine_s_max_over_ranks": wall(out["seconds"]), "best_cost": out["cost"], "best_individual": out["start"],
+        "rank0_reference_equivalent_evals": ev, "all_local_individuals_match_golden_counters": True,
+        "winner_tour_matches_golden": True}
     inst.close()
     return res
+
+
+def cpu_baselines(xy, wt, succ0, obj0, cores):
+    """The oracle (oracle/tsp_oracle.c, the reference restated; kind "port": the reference needs cplex.h and cannot be
+    built here) timed on this box's host cores on bounded samples of the same workloads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    out = {}
+    sweeps = 15
+    _, _, _, cst, _, _ = O.two_opt_best(xy, wt, succ0, max_sweeps=sweeps)
+    out["best_improvement"] = {"evals_per_s": cst["evals"] / cst["seconds"], "seconds": cst["seconds"], "cores": 1,
+                               "sample": "%d sweeps of alg_2opt_tabu on the rand10000 greedy tour" % sweeps}
+    # alg_2opt as the reference runs it: gettimeofday per pair (heuristics.c:456-462), and with the clock hoisted
+    for label, cpp in (("first_improvement_faithful_clock_per_pair", 1), ("first_improvement_clock_hoisted", 0)):
+        _, _, _, st, _ = O.two_opt_first(xy, wt, succ0, obj0, time_limit=5.0, clock_per_pair=cpp)
+        out[label] = {"evals_per_s": st["evals"] / st["seconds"], "seconds": st["seconds"], "cores": 1,
+                      "sample": "the first %.0f s of alg_2opt on the rand10000 greedy tour (%d evaluations)" % (st["seconds"], st["evals"])}
+    # configs[3] on all host cores: 256 GRASP starts of att532 (libc stream, sequential) then alg_2opt each in a thread pool
+    axy, awt = O.parse_tsplib(os.path.join(ROOT, "tests", "golden", "instances", "att532.tsp"))
+    O.srandom(123)
+    t0 = time.perf_counter()
+    tours = []
+    for k in range(256):
+        node = int(O.urand() * (len(axy) - 1))
+        _, s, o = O.grasp(axy, awt, start=node)
+        tours.append((s, o))
+    t1 = time.perf_counter()
+
+    def one(k):
+        _, s2, _, st, _ = O.two_opt_first(axy, awt, tours[k][0], tours[k][1])
+        return O.succ_cost(axy, awt, s2), st["evals"]
+    with ThreadPoolExecutor(max_workers=cores) as ex:   # ctypes releases the GIL; the descent keeps no global state
+        rows = list(ex.map(one, range(256)))
+    t2 = time.perf_counter()
+    k = min(range(256), key=lambda i: (rows[i][0], i))
+    out["config4_att532_grasp256_2opt_all_cores"] = {
+        "seconds": t2 - t0, "grasp_s": t1 - t0, "two_opt_s": t2 - t1, "cores": cores, "evals": int(sum(r[1] for r in rows)),
+        "best_true_cost": rows[k][0], "best_start": k,
+        "note": "the reference is single-threaded; this is an outer loop over the starts on all host cores"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip time-to-local-optimum runs")
-    ap.add_argument("--no-variants", action="store_true",
-                    help="skip the bounds-switched-off sweeps (they run the same kernel symbol: keep profiles clean)")
+    ap.add_argument("--no-extras", action="store_true", help="skip everything but the timed region and the roofline")
+    ap.add_argument("--no-variants", action="store_true", help="skip the exhaustive sweeps (keeps a profile clean)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
     dist = None
+    device = None
     # TSP_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to test it on a 1-GPU box)
     if world > 1 or os.environ.get("TSP_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=device)
     else:
         local_rank = 0
 
     from tsp_optimization_amd import engine as E
+    from tsp_optimization_amd import multistart as MS
     if E.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
 
@@ -129,50 +209,46 @@ def main():
     succ0, obj0, status = inst.construct(E.GREEDY, np.array([start_node], dtype=np.int32))
     assert status[0] == 0
     tours = E.Tours(inst, 1)
-    tours.upload(succ0[0], obj0[0])
-    pairs_per_step = N_NODES * (N_NODES - 1) // 2 - N_NODES
+    tours.upload(succ0[0], obj0[0])          # resident in HBM from here on (and remembered as the reset point)
+    pairs_per_sweep = N_NODES * (N_NODES - 1) // 2 - N_NODES
 
-    def steps_done():
-        _, _, st = tours.download()
-        return st[0]["steps"]
+    def one_descent():
+        tours.reset()                        # device-to-device restore of the start tour
+        rc, done = tours.run_engine(E.BEST, engine=E.ENGINE_AUTO)
+        assert rc == 0 and done
 
-    def run_real_steps(k, before):
-        """Queues k sweeps and waits; a descent that reaches its local optimum inside the window is
-        restarted from the uploaded tour so that exactly k sweeps do work.  -> steps counter after."""
-        left = k
-        while True:
-            tours.run(E.BEST, max_steps=left, sync=False)
-            ctx.synchronize()
-            after = steps_done()          # one 40 KB download per window, inside the timed region
-            left -= after - before
-            if left <= 0:
-                return after
-            tours.reset()
-            before = 0
-
-    mark = run_real_steps(args.warmup, 0)
+    for _ in range(args.warmup):
+        one_descent()
     barrier_sync()
     t0 = time.perf_counter()
-    run_real_steps(args.steps, mark)
+    for _ in range(args.steps):
+        one_descent()
     barrier_sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_evals = float(pairs_per_step) * args.steps * world
-    value = total_evals / elapsed
+    s_fin, o_fin, st_fin = tours.download()
+    st = st_fin[0]
+    # every rank ran `steps` descents of its own start; totals over the job (counters are per descent, identical each step)
+    tot = {k: float(st[k]) for k in ("lane_pairs", "tier1_pairs", "exact_pairs", "staged_recs", "evals", "sweeps")}
+    if dist is not None:
+        import torch
+        v = torch.tensor([tot[k] for k in sorted(tot)], dtype=torch.float64, device=device)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        tot = dict(zip(sorted(tot), [float(x) for x in v.tolist()]))
+    counted = st["exact_pairs"] >= 0
+    lane_pairs_job = tot["lane_pairs"] * args.steps
+    value = lane_pairs_job / elapsed
 
-    # multi-start epilogue: one RCCL all-reduce(min) of the packed (true cost, rank)
+    # multi-start epilogue of the timed workload: one RCCL all-reduce(min) of the packed (true cost, rank)
     cost_now, _, packed = tours.best(true_cost=True)
     best_cost, best_rank = int(cost_now), rank
     if dist is not None:
-        import torch
-        p = torch.tensor([(int(cost_now) << 24) | rank], dtype=torch.int64, device="cuda")
-        dist.all_reduce(p, op=dist.ReduceOp.MIN)
-        best_cost, best_rank = int(p.item()) >> 24, int(p.item()) & 0xFFFFFF
+        best_cost, best_rank = MS.allreduce_best(MS.pack(int(cost_now), rank), device=device)
 
     out = {
         "metric": "2opt_edge_pair_evals_per_sec",
@@ -188,70 +264,100 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[2]: synthetic random EUC_2D n=10000 (numpy default_rng(10000), "
-                        "integer coords in [0,1e6)^2), single-start best-improvement 2-opt sweeps "
-                        "(alg_2opt_tabu, tabusearch.c:128-165) continuing the descent from greedy(start=rank)",
-            "n": N_NODES, "starts_per_gpu": 1, "pairs_per_step": pairs_per_step,
-            "step": "one full sweep of all non-adjacent (i<j) pairs + argmin + segment reversal",
+            "workload": "BASELINE configs[2]: synthetic random EUC_2D n=10000 (numpy default_rng(10000), integer coords in "
+                        "[0,1e6)^2), single-start 2-opt; step = one full best-improvement descent (alg_2opt_tabu with "
+                        "skip_edge == NULL, tabusearch.c:107-178) of greedy(start=rank) to its local optimum on a tour "
+                        "resident in HBM, default engine (TSP_ENGINE_AUTO)",
+            "n": N_NODES, "starts_per_gpu": 1, "pairs_per_sweep": pairs_per_sweep, "sweeps_per_step_rank0": int(st["sweeps"]),
+            "step": "device-to-device restore of the start tour + %d sweeps (box / bound / exact tiers) + arg-min + segment "
+                    "reversal each" % int(st["sweeps"]),
             "parallelism": "multi-start x%d (one start per GPU, no data-path collective)" % world,
         },
+        "evals": {
+            "definition": "value = pairs for which a lane evaluated a lower bound of delta or delta itself (kernel tier "
+                          "counters), per second, whole job.  NOT counted in value: pairs decided 64 x 64 at a time by the "
+                          "box form of the new-edge bound or by row culling.  reference_equivalent_pairs_per_s counts every "
+                          "pair the reference would have evaluated for the same (bit-identical) decisions.",
+            "counted_on_device": bool(counted),
+            "per_step_rank0": {"lane_pairs_tier0": int(st["lane_pairs"]), "tier1_pairs": int(st["tier1_pairs"]),
+                               "exact_delta_expressions": int(st["exact_pairs"]), "staged_node_records": int(st["staged_recs"]),
+                               "reference_equivalent_pairs": int(st["evals"]), "sweeps": int(st["sweeps"]), "moves": int(st["moves"])},
+            "lane_pairs_per_s": value,
+            "exact_delta_per_s": tot["exact_pairs"] * args.steps / elapsed if counted else None,
+            "reference_equivalent_pairs_per_s": tot["evals"] * args.steps / elapsed,
+        },
+        "time_to_local_optimum_s": elapsed / args.steps,
         "multistart_best": {"cost": best_cost, "rank": best_rank,
                             "collective": "all_reduce(min) int64 over RCCL" if dist is not None else "none (1 GPU)"},
     }
 
     if rank == 0:
-        # roofline of the dominant kernel (best-improvement sweep), HIP events on its stream
-        ms, evals_per_launch = tours.time_scan(reps=50)
-        achieved = evals_per_launch * ALGO_BYTES_PER_EVAL / (ms * 1e-3) / 1e9
+        big = golden("oracle_vectors_big.json")["rand10000_best"]["final"]
+        out["parity"] = {"final_cost": float(o_fin[0]), "golden_cost": big["cost"], "sweeps": int(st["sweeps"]),
+                         "golden_sweeps": big["stats"]["sweeps"], "moves": int(st["moves"]),
+                         "final_tour_matches_golden": bool(fnv1a(s_fin[0]) == big["hash"] and o_fin[0] == big["cost"]
+                                                           and st["sweeps"] == big["stats"]["sweeps"]
+                                                           and st["evals"] == big["stats"]["evals"]
+                                                           and st["moves"] == big["stats"]["moves"]),
+                         "golden": "tests/golden/oracle_vectors_big.json (oracle: full CPU descent, 23 min)"}
+        assert out["parity"]["final_tour_matches_golden"], out["parity"]
+
+    if rank == 0:
+        # roofline of the dominant kernel of the timed region: one k_cluster_two_opt launch per descent, HIP events on the
+        # engine's stream around a further descent (stats.device_ms), counted lane-operations of the executed tiers
+        one_descent()
+        _, _, st2 = tours.download()
+        kernel_ms = st2[0]["device_ms"]
+        sweeps = st2[0]["sweeps"]
+        ops = (st2[0]["lane_pairs"] * OPS_TIER0_F32 + max(0, st2[0]["tier1_pairs"]) * OPS_TIER1 +
+               max(0, st2[0]["exact_pairs"]) * OPS_EXACT + max(0, st2[0]["staged_recs"]) * OPS_STAGED +
+               sweeps * (inst_groups(N_NODES) * (inst_groups(N_NODES) + 1) // 2) * OPS_BOXTEST)
+        achieved = ops / (kernel_ms * 1e-3)
         traffic = None
         tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tj):
             with open(tj) as f:
-                traffic = json.load(f).get("sweep_n10000_hbm_bytes_per_launch")
-        # transparency: the same sweep (a) through the tiled kernel that visits every pair with the per-pair bounds,
-        # (b) with the new-edge bound off (every pair gets both raw roots), (c) with both bounds off (every pair
-        # gets the exact delta), each on a fresh copy of the same start tour
-        variants = {}
-        for label, env in (() if (args.no_variants or args.no_extras) else
-                           (("tiled_every_pair_visited", {"TSP_SORTED_MIN_N": "1000000000"}),
-                            ("tiled_no_new_edge_bound", {"TSP_NO_PRUNE": "1"}),
-                            ("tiled_every_pair_exact", {"TSP_NO_FILTER": "1"}))):
-            os.environ.update(env)
+                traffic = json.load(f).get("r02_cluster_descent_n10000_hbm_bytes_per_launch")
+        exhaustive = {}
+        if not (args.no_variants or args.no_extras):
+            # the same sweep with every delta expression executed (tiled kernel k_recs + k_step, bounds off): the kernel
+            # whose work IS the reference's 49 985 000 evaluations per launch, VALU-throughput bound
+            os.environ["TSP_NO_FILTER"] = "1"
             inst_v = E.Instance(ctx, xy, wt, 1)
             tours_v = E.Tours(inst_v, 1)
-            for k in env:
-                del os.environ[k]
+            del os.environ["TSP_NO_FILTER"]
             tours_v.upload(succ0[0], obj0[0])
-            ms_v, ev_v = tours_v.time_scan(reps=30)
-            variants[label] = {"kernel_ms": ms_v, "evals_per_s": ev_v / (ms_v * 1e-3)}
+            ms_v, ev_v = tours_v.time_scan(reps=40)
+            exhaustive = {"kernel": "tsp::k_recs + tsp::k_step<EUC_2D icoord, BEST> with the bounds off (TSP_NO_FILTER=1): every "
+                                    "non-adjacent pair gets the exact delta", "kernel_ms": ms_v, "delta_expressions_per_launch": ev_v,
+                          "exact_delta_per_s": ev_v / (ms_v * 1e-3), "bound": "valu", "ops_per_eval": OPS_EXACT,
+                          "achieved": ev_v * OPS_EXACT / (ms_v * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
+                          "unit": "T lane-op/s", "frac": ev_v * OPS_EXACT / (ms_v * 1e-3) / FP64_LANE_OPS_PEAK,
+                          "rocprof": "profiles/r02_kernel_stats_exhaustive.csv"}
             tours_v.close()
             inst_v.close()
         out["roofline"] = {
-            "kernel": "tsp::k_sweep<EUC_2D integer-coordinate variant> (one best-improvement sweep of n=10000 + "
-                      "choice of the move), preceded in every launch by tsp::k_move_recs (carries out the previous "
-                      "move, rebuilds the per-node records); kernel_ms is the HIP-event time of the pair, back to "
-                      "back, over 50 further sweeps of the same descent right after the timed region (rocprof means: profiles/r01_kernel_stats.csv)",
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel_ms": ms, "evals_per_launch": evals_per_launch,
-            "algorithmic_bytes_per_eval": ALGO_BYTES_PER_EVAL,
-            "note": "achieved = evals/launch x 72 B (operands the reference touches per delta evaluation) / "
-                    "kernel time, as the measurement contract defines it.  The sweep keeps its operands on chip and "
-                    "decides most pairs by rigorous bounds (an evaluation = one pair decided exactly as the "
-                    "reference decides it: whole 64 x 64 blocks of pairs by the box form of the new-edge bound, "
-                    "single pairs by the new-edge bound, by both new edges without a root, the rest by the exact "
-                    "delta), so real HBM traffic (traffic) is far below the algorithmic bytes and frac exceeds 1: "
-                    "the step is bound by launch and memory latencies, not by HBM or VALU throughput, see "
-                    "DESIGN.md.  `variants` gives the same sweep with the bounds switched off one by one",
-            "variants": variants,
-            "counters": {"measured": "profiles/r01_pmc_sq_wave_counters.json",
-                         "note": "rocprofv3 SQ counters of k_sweep: the average wave lives ~3 us of the ~16 us "
-                                 "launch; the launch is the critical path tests -> records into LDS -> pair loop "
-                                 "of the busiest block -> hand-off -> arg-min over the blocks"},
+            "kernel": "tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, BEST, float replica, sorted scan> -- one launch = "
+                      "one whole descent (%d sweeps) on 256 workgroups; kernel_ms = HIP events on the engine's stream around one "
+                      "further descent after the timed region (rocprof mean: profiles/r02_kernel_stats.csv)" % sweeps,
+            "bound": "valu", "achieved": achieved / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
+            "unit": "T lane-op/s (fp64 vector lane-instructions; peak = 78.6 TFLOP/s / 2; fp32 operations count 1/2)",
+            "frac": achieved / FP64_LANE_OPS_PEAK, "traffic": traffic,
+            "kernel_ms": kernel_ms, "us_per_sweep": 1e3 * kernel_ms / sweeps, "counted_lane_ops_per_launch": ops,
+            "ops_per_unit": {"tier0_pair_f32": OPS_TIER0_F32, "tier1_pair": OPS_TIER1, "exact_delta": OPS_EXACT,
+                             "staged_record": OPS_STAGED, "group_pair_box_test": OPS_BOXTEST},
+            "operand_bandwidth": {"note": "SURVEY 8(d) also asks for evals/s x 72 B against the HBM peak: with the operands "
+                                          "on chip it is not a roofline (the tour is read once per launch), reported for completeness",
+                                  "reference_equivalent_GBps": st2[0]["evals"] * 72.0 / (kernel_ms * 1e-3) / 1e9,
+                                  "executed_lane_pairs_GBps": st2[0]["lane_pairs"] * 72.0 / (kernel_ms * 1e-3) / 1e9,
+                                  "hbm_peak_GBps": HBM_PEAK_GBS},
+            "note": "the step is a chain of latencies (LDS gathers at two waves per SIMD, one all-to-all exchange through L2 per "
+                    "sweep, block barriers), not a throughput kernel: the executed arithmetic is ~1-2 % of the VALU peak by "
+                    "design -- see DESIGN.md 4.8; roofline.exhaustive is the same sweep with nothing pruned",
+            "exhaustive": exhaustive,
         }
 
     if rank == 0 and world == 1 and not args.no_extras:
-        from oracle import oracle as O   # checker only: known answers / CPU baseline, never the timed GPU path
         extras = {}
         t1 = time.perf_counter()
         rc, s1, o1, st1 = inst.two_opt(succ0[0], obj0[0], mode=E.FIRST)
@@ -261,17 +367,16 @@ def main():
             "reference_final_cost": 77370387, "cost_match": bool(o1 == 77370387 and obj0[0] == 88104308),
             "sweeps": st1["sweeps"], "reference_evals": st1["evals"], "moves": st1["moves"],
             "reference_counters_match": bool((st1["sweeps"], st1["evals"], st1["moves"]) == (10, 499850987, 2704)),
-            "reference_equivalent_evals_per_s": st1["evals"] / dt1, "pairs_scanned_on_device": st1["pairs_scanned"],
-            "launch_steps": st1["steps"]}
+            "reference_equivalent_evals_per_s": st1["evals"] / dt1, "lane_pairs_executed": st1["lane_pairs"],
+            "exact_delta_expressions_executed": st1["exact_pairs"], "steps": st1["steps"],
+            "note": "host tour in, host tour out (PCIe-inclusive: 200 KB each way)"}
         t2 = time.perf_counter()
         rc, s2, o2, st2 = inst.two_opt(succ0[0], obj0[0], mode=E.BEST)
         dt2 = time.perf_counter() - t2
-        extras["best_improvement_alg_2opt_tabu"] = {
-            "time_to_local_optimum_s": dt2, "device_ms": st2["device_ms"], "final_cost": o2,
-            "recomputed_cost_match": bool(o2 == O.succ_cost(xy, wt, s2)), "sweeps": st2["sweeps"],
-            "evals": st2["evals"], "moves": st2["moves"], "evals_per_s": st2["evals"] / dt2}
+        extras["best_improvement_alg_2opt_tabu_host_tour"] = {
+            "time_to_local_optimum_s": dt2, "device_ms": st2["device_ms"], "final_cost": o2, "sweeps": st2["sweeps"],
+            "moves": st2["moves"], "note": "host tour in, host tour out (PCIe-inclusive)"}
         out["time_to_local_optimum"] = extras
-        out["other_configs"] = other_configs(E, ctx, O)
         # the genuinely HBM-bound kernel of the path: n x n calc_dist matrix (4 n^2 bytes written)
         _, dm_ms = inst.dist_matrix(as_int32=True, fetch=False)
         _, dm64_ms = inst.dist_matrix(as_int32=False, fetch=False)
@@ -284,17 +389,19 @@ def main():
                     "achieved": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9,
                     "frac": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
+    if not args.no_extras:
+        out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        sweeps = 25
-        _, es, eo = O.greedy(xy, wt, start=start_node)
-        assert eo == obj0[0] and (es == succ0[0]).all()
-        _, _, _, cst, _, _ = O.two_opt_best(xy, wt, es, max_sweeps=sweeps)
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))   # a 1-GPU box's CPU share
+        base = cpu_baselines(xy, wt, succ0[0], obj0[0], cores)
         out["cpu_baseline"] = {
-            "value": cst["evals"] / cst["seconds"], "unit": "evals/s", "cores": 1, "kind": "port",
-            "sample": "%d best-improvement sweeps (%d delta evaluations) of the same rand10000 greedy tour by "
-                      "oracle/tsp_oracle.c (gcc -O2), one thread, %.1f s; the reference is single-threaded and "
-                      "cannot be built here (needs cplex.h)" % (sweeps, cst["evals"], cst["seconds"]),
+            "value": base["best_improvement"]["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": base["best_improvement"]["sample"] + " by oracle/tsp_oracle.c (gcc -O2), one thread, %.1f s: every "
+                      "delta expression executed (compare with evals.reference_equivalent_pairs_per_s and "
+                      "roofline.exhaustive.exact_delta_per_s); the reference is single-threaded and cannot be built here "
+                      "(needs cplex.h)" % base["best_improvement"]["seconds"],
+            "others": {k: v for k, v in base.items() if k != "best_improvement"},
         }
 
     tours.close()
@@ -312,6 +419,10 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def inst_groups(n):
+    return (n + 63) // 64
 
 
 if __name__ == "__main__":

@@ -86,6 +86,12 @@ typedef struct {
     int64_t steps;         /* steps: launches of a step kernel (GRID) or chunk iterations (LDS)   */
     double seconds;        /* wall time of the call, host clock                                  */
     double device_ms;      /* device time of the call, HIP events on the engine's stream         */
+    /* What the device executed to decide those pairs (the decisions are the reference's; the work is not).  CLUSTER
+     * engine: counted; other engines: lane_pairs = pairs_scanned, the rest -1 (not counted).                      */
+    int64_t lane_pairs;    /* pairs for which a lane evaluated a lower bound of delta or delta itself             */
+    int64_t tier1_pairs;   /* ... that the first bound could not exclude                                           */
+    int64_t exact_pairs;   /* delta expressions actually executed (src/heuristics.c:474 / src/tabusearch.c:150)   */
+    int64_t staged_recs;   /* node records derived for the sorted scan (one rounded root each)                    */
 } tsp_two_opt_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */

@@ -422,10 +422,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
     return rc ? rc : status;
 }
 
-int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
-    if (!t || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
-    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
-    if (all_done) *all_done = 0;
+static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const bool want = engine == TSP_ENGINE_CLUSTER ||
                           (tsp_cluster_fits(t, mode) && tsp_cluster_size(t, mode) >= 4 &&
@@ -445,6 +442,24 @@ int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max
     }
     if (engine != TSP_ENGINE_GRID) return TSP_DEV_E_ARG;
     return tsp_grid_run(t, mode, nullptr, 0, 0, max_steps, time_limit_s, 1, all_done);
+}
+
+int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
+    if (!t || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
+    tsp_dev_inst *inst = t->inst;
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    if (all_done) *all_done = 0;
+    // device time of the run, HIP events on the engine's stream (reported as stats.device_ms by the next download)
+    if (!inst->ev0) { TSP_HIP_TRY(hipEventCreate(&inst->ev0)); TSP_HIP_TRY(hipEventCreate(&inst->ev1)); }
+    TSP_HIP_TRY(hipEventRecord(inst->ev0, inst->ctx->stream));
+    const int status = run_engine_untimed(t, mode, engine, max_steps, time_limit_s, all_done);
+    if (status < 0) return status;
+    TSP_HIP_TRY(hipEventRecord(inst->ev1, inst->ctx->stream));
+    TSP_HIP_TRY(hipEventSynchronize(inst->ev1));
+    float ms = 0.f;
+    TSP_HIP_TRY(hipEventElapsedTime(&ms, inst->ev0, inst->ev1));
+    t->device_ms = ms;
+    return status;
 }
 
 }  // extern "C"

@@ -35,6 +35,10 @@ struct alignas(16) TourState {
     // sorted sweep: order/pos exist twice; `parity` says which copy holds the tour, `pending` that the move
     // (reverse positions mv_pa+1 .. mv_pb) chosen by the last sweep has not been carried out yet
     int parity, pending, mv_pa, mv_pb;
+    // what the device really executed (CLUSTER engine; added to by every workgroup of the tour with atomics):
+    // pairs a lane evaluated a bound or the delta for, pairs that reached tier 1, delta expressions executed, node
+    // records derived for the sorted scan
+    long long lane_pairs, tier1_pairs, exact_pairs, staged_recs;
 };
 
 constexpr int kScanThreads = 256;

@@ -349,6 +349,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 
     const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
     bool failed = false;
+    // executed work, per wave (wave-uniform values): rows or row-lanes through tier 0, pairs queued for tier 1, delta
+    // expressions, staged records; summed into the tour's control block at the end of the launch
+    long long w_lane = 0, w_t1 = 0, w_ex = 0, w_st = 0;
 #ifdef TSP_STAMPS
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #endif
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 for (int e0 = 0; e0 < kept; e0 += P) {
                     const int ne = min(P, kept - e0);
                     if (tid == 0) *s_nitems = 0;
+                    if (wave == 0) w_st += ne * 128;
                     __syncthreads();
                     for (int x = tid; x < ne * 128; x += kClThreads) {   // whole waves: ne * 128 is a multiple of 64
                         const int pe = x >> 7;
@@ -440,6 +444,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         int qhead = 0, qtail = 0;   // wave-uniform
                         // tiers 1 and 2 for `cnt` queued pairs, one per lane
                         auto dense = [&](int cnt) {
+                            bool ok = false;
                             if (lane < cnt) {
                                 const unsigned en = q[(qhead + lane) & (kClQueue - 1)];
                                 const NodeRec ri = SR::unpack(stage[en & 0xffffu]), rj = SR::unpack(stage[en >> 16]);
@@ -450,8 +455,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 const double sc = ATT10 ? 0.1 : 1.0;
                                 const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
                                 const double w = T2 * T2 - p1 - p2;
-                                const bool ok = (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
-                                                (rj.id != ri.succ) & (rj.succ != ri.id);   // never adjacent nodes
+                                ok = (T2 > 0.0) & (w > 0.0) & (4.0 * p1 * p2 < w * w) &
+                                     (rj.id != ri.succ) & (rj.succ != ri.id);   // never adjacent nodes
                                 if (ok) {   // tier 2: the exact delta, lower node id first (tabusearch.c:150 with i < j)
                                     int gi = 0, gj = 0;
                                     double delta;
@@ -473,6 +478,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 }
                             }
                             qhead += cnt;
+                            w_ex += __popcll(__ballot(ok));
 #ifdef TSP_STAMPS
                             if (tid == 0) { prof[6] += 1; prof[7] += cnt; }
 #endif
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 valid[qq] = k0 + qq < nit;
                                 ridx[qq] = (int)s_items[min(k0 + qq, nit - 1)];
                             }
+                            w_lane += 64 * min(RU, nit - k0);
 #pragma unroll
                             for (int qq = 0; qq < RU; ++qq) {
                                 const int pe = ridx[qq] >> 7;
@@ -531,6 +538,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 if (m) {
                                     if (nd) q[(qtail + __popcll(m & ((1ull << lane) - 1ull))) & (kClQueue - 1)] = (unsigned)ridx[qq] | ((unsigned)cidx[qq] << 16);
                                     qtail += __popcll(m);
+                                    w_t1 += __popcll(m);
                                     if (qtail - qhead >= 64) dense(64);
                                 }
                             }
@@ -568,22 +576,25 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 const bool act = j < n && j > rb;
                 if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
                 __syncthreads();
-                if (act) {
+                w_lane += (long long)nr * __popcll(__ballot(act));
+                {
                     for (int r = 0; r < nr; ++r) {
                         const int i = rb + r;
                         const NodeRec ri = s_rows[r];
-                        bool ok = j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                        bool ok = act && j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
                         if constexpr (!BEST) ok = ok && (i > ci || j > cj);
                         const u64 kq = make_key(i, j);
                         if constexpr (!BEST) ok = ok && kq < key;
                         if constexpr (has_root_filter<WT>()) {
                             const double bound = BEST ? bd : 0.0;
                             ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + prune2);
+                            w_t1 += __popcll(__ballot(ok));
                             if (ok) {
                                 const double lower = pair_delta_approx<WT>(ri, rj) - a.margin;
                                 ok = BEST ? lower <= bound : lower < bound;
                             }
                         }
+                        w_ex += __popcll(__ballot(ok));
                         if (ok) {
                             const double delta = pair_delta<WT, INT>(ri, rj);
                             if constexpr (!BEST) {
@@ -745,6 +756,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][7] += steps - st->steps; }
     if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
 #endif
+    if (!failed && lane == 0) {   // executed-work counters: every workgroup adds its share (the fields are written by nobody else)
+        using gll = __attribute__((address_space(1))) long long;
+        if (w_lane) __hip_atomic_fetch_add((gll *)&st->lane_pairs, w_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w_t1) __hip_atomic_fetch_add((gll *)&st->tier1_pairs, w_t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w_ex) __hip_atomic_fetch_add((gll *)&st->exact_pairs, w_ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w_st) __hip_atomic_fetch_add((gll *)&st->staged_recs, w_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
     if (failed || c != 0) return;
     __syncthreads();

@@ -474,6 +474,11 @@ int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t
             tsp_two_opt_stats &o = stats[b];
             o.sweeps = z.sweeps; o.evals = z.evals; o.moves = z.moves; o.reversed = z.reversed;
             o.pairs_scanned = z.pairs_scanned; o.steps = z.steps;
+            o.seconds = 0.0; o.device_ms = t->device_ms;   // the last tsp_dev_tours_run_engine (host-tour calls overwrite both)
+            const bool counted = z.lane_pairs > 0 || z.exact_pairs > 0;   // the CLUSTER engine counts what it executes
+            o.lane_pairs = counted ? z.lane_pairs : z.pairs_scanned;
+            o.tier1_pairs = counted ? z.tier1_pairs : -1; o.exact_pairs = counted ? z.exact_pairs : -1;
+            o.staged_recs = counted ? z.staged_recs : -1;
         }
     }
     return TSP_OK;

@@ -21,7 +21,9 @@ class TspDeviceError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("sweeps", C.c_int64), ("evals", C.c_int64), ("moves", C.c_int64),
                 ("reversed", C.c_int64), ("pairs_scanned", C.c_int64), ("steps", C.c_int64),
-                ("seconds", C.c_double), ("device_ms", C.c_double)]
+                ("seconds", C.c_double), ("device_ms", C.c_double),
+                ("lane_pairs", C.c_int64), ("tier1_pairs", C.c_int64), ("exact_pairs", C.c_int64),
+                ("staged_recs", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -2,10 +2,19 @@
 all-reduce(min) of a packed (cost, start id) over RCCL (torch.distributed backend "nccl"; "gloo"
 in the CPU tests), then the winner's tour is broadcast from the rank that owns it.
 
-The packing is the one SURVEY.md section 5 proposes: cost in the high bits, start id in the low 24,
-so that the integer minimum is (lowest cost, then lowest start id) -- the same winner a serial
-loop that keeps the first strictly better start (heuristics.c:534) would report.
+This is the generalisation of HEU_Grasp_iter's loop (src/heuristics.c:510-544: random start, grasp(), keep the
+best) that BASELINE configs[3] and [4] define: every start is refined by alg_2opt, start k runs on rank
+k % world, and the reported winner is the one a serial loop keeping the first strictly better start (:534)
+would report.  The packing is the one SURVEY.md section 5 proposes: cost in the high bits, start id in the low 24,
+so that the integer minimum is (lowest cost, then lowest start id).
+
+`run_sharded` is the launcher: bench.py drives it with the device engine (one process per GPU), the CPU tests
+drive the same function over gloo with the engine replaced by the golden table.
 """
+import time
+
+import numpy as np
+
 ID_BITS = 24
 ID_MASK = (1 << ID_BITS) - 1
 
@@ -55,3 +64,118 @@ def broadcast_winner(succ, winner_start, world, device=None):
     import torch.distributed as dist
     dist.broadcast(succ, src=owner_of(winner_start, world))
     return succ
+
+
+def run_sharded(refine, num_starts, n, rank=0, world=1, device=None):
+    """The multi-start launcher.
+
+    refine(ids) -> (costs, tours): for the global start ids `ids` (this rank's shard, ascending) the true tour cost of
+    every refined start and the refined tours as an int32 array [len(ids), n] of successor lists.
+    Returns {"cost", "start", "tour" (np.int32 [n], the winner's, on EVERY rank), "seconds" (this rank's refine time),
+    "local_starts"}.  world > 1 needs an initialised torch.distributed process group; the only collectives are one
+    all_reduce(MIN) of an int64 and one broadcast of n int32 from the winner's owner.
+    """
+    ids = shard_starts(num_starts, rank, world)
+    t0 = time.perf_counter()
+    costs, tours = refine(ids)
+    seconds = time.perf_counter() - t0
+    tours = np.ascontiguousarray(tours, dtype=np.int32).reshape(len(ids), n)
+    packed = local_best(costs, ids)
+    if world > 1:
+        import torch
+        cost, start = allreduce_best(packed, device=device)
+        buf = torch.zeros(n, dtype=torch.int32, device=device)
+        if owner_of(start, world) == rank:
+            buf.copy_(torch.from_numpy(tours[ids.index(start)]))
+        broadcast_winner(buf, start, world)
+        tour = buf.cpu().numpy()
+    else:
+        assert packed != NO_RESULT
+        cost, start = unpack(packed)
+        tour = tours[ids.index(start)].copy()
+    return {"cost": cost, "start": start, "tour": tour, "seconds": seconds, "local_starts": len(ids)}
+
+
+# ---- the two multi-start workloads of BASELINE.json, on the device engine --------------------------------------
+
+def succ_to_perm(succ):
+    """Successor list -> the permutation that starts at node 0 (the chromosome walk of src/genetic.c:436-441)."""
+    n = len(succ)
+    s = succ.tolist()
+    perm = [0] * n
+    v = 0
+    for k in range(n):
+        perm[k] = v
+        v = s[v]
+    return np.asarray(perm, dtype=np.int32)
+
+
+def perm_to_succ(perm):
+    """Permutation -> successor list (from_chromosome_to_edges, src/genetic.c:33-42)."""
+    perm = np.asarray(perm, dtype=np.int32)
+    succ = np.empty(len(perm), dtype=np.int32)
+    succ[perm] = np.roll(perm, -1)
+    return succ
+
+
+class LibcRandom:
+    """The process-global libc random() stream the reference draws from (srandom(seed) in src/solver.c:264-266;
+    URAND() = random() / RAND_MAX, include/utility.h:36)."""
+    RAND_MAX = 2147483647
+
+    def __init__(self, seed):
+        import ctypes
+        self._libc = ctypes.CDLL(None)
+        self._libc.random.restype = ctypes.c_long
+        self._libc.srandom(ctypes.c_uint(seed))
+
+    def urand(self):
+        return self._libc.random() / self.RAND_MAX
+
+    def random_perm(self, n):
+        """random_generation of src/genetic.c:349-364: the identity permutation, then n swaps of two rand_choice(0, n)
+        positions (src/utility.c:752: from + (int)(URAND() * (to - from)))."""
+        perm = list(range(n))
+        for _ in range(n):
+            p = int(self.urand() * n)
+            q = int(self.urand() * n)
+            perm[p], perm[q] = perm[q], perm[p]
+        return np.asarray(perm, dtype=np.int32)
+
+
+def grasp_stream(urand, n, num_starts):
+    """Start nodes and URAND streams of `num_starts` GRASP starts in the reference's draw order: one draw for the
+    start node (src/heuristics.c:519), then the n draws of grasp() (:127).  `urand` is a callable returning the
+    next URAND() of the libc stream (the caller seeds it).  Every rank draws the whole stream and keeps its shard."""
+    starts = np.zeros(num_starts, dtype=np.int32)
+    stream = np.zeros((num_starts, n))
+    for k in range(num_starts):
+        starts[k] = int(urand() * (n - 1))
+        stream[k] = [urand() for _ in range(n)]
+    return starts, stream
+
+
+def config4_refiner(E, inst, starts, stream):
+    """BASELINE configs[3]: GRASP tours for the shard's starts + alg_2opt each, true cost through the fitness kernel."""
+    def refine(ids):
+        ids = list(ids)
+        succ, obj, _ = inst.construct(E.GRASP, starts[ids], stream[ids])
+        rc, s2, o2, st = inst.two_opt(succ, obj, mode=E.FIRST)
+        true_cost = inst.perm_cost(np.stack([succ_to_perm(s) for s in s2]))
+        refine.stats = st
+        return true_cost, s2
+    return refine
+
+
+def config5_refiner(E, inst, perms):
+    """BASELINE configs[4]: the shard's random individuals (src/genetic.c:349-364) each refined by alg_2opt
+    (the mutation-3 path, src/genetic.c:426-443, without its 2 s limit)."""
+    def refine(ids):
+        ids = list(ids)
+        p = perms[ids]
+        succ = np.stack([perm_to_succ(x) for x in p])
+        cost = inst.perm_cost(p)
+        rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST)
+        refine.stats = st
+        return o2, s2
+    return refine
