@@ -319,7 +319,7 @@ def main():
             with open(tj) as f:
                 traffic = json.load(f).get("r02_cluster_descent_n10000_hbm_bytes_per_launch")
         exhaustive = {}
-        if not (args.no_variants or args.no_extras):
+        if not args.no_variants:
             # the same sweep with every delta expression executed (tiled kernel k_recs + k_step, bounds off): the kernel
             # whose work IS the reference's 49 985 000 evaluations per launch, VALU-throughput bound
             os.environ["TSP_NO_FILTER"] = "1"

@@ -131,15 +131,16 @@ from tsp_optimization_amd import multistart as M
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo")
 table = json.load(open(os.path.join(sys.argv[1], "tests/golden/oracle_vectors.json")))["att532_multistart256"]
-mine = M.shard_starts(len(table), rank, world)
-# the per-start 2-opt results stand in for what each rank's GPU produced (golden table, oracle-generated)
-packed = M.local_best([table[k]["opt_true"] for k in mine], mine)
-cost, start = M.allreduce_best(packed)
-succ = torch.zeros(8, dtype=torch.int32)
-if M.owner_of(start, world) == rank:
-    succ[:] = torch.tensor([(table[start]["hash"] >> (8 * b)) & 0x7f for b in range(8)], dtype=torch.int32)
-M.broadcast_winner(succ, start, world)
-print(json.dumps({"rank": rank, "n_mine": len(mine), "cost": cost, "start": start, "succ": succ.tolist()}))
+n = 532
+calls = []
+def refine(ids):
+    # the engine of one rank, replaced by the golden table (oracle-generated): true cost per start, and a stand-in tour
+    # that encodes the start id so that the broadcast can be checked
+    calls.append(list(ids))
+    return [table[k]["opt_true"] for k in ids], np.stack([np.full(n, k, dtype=np.int32) for k in ids])
+out = M.run_sharded(refine, len(table), n, rank, world)       # the launcher bench.py drives on the GPUs
+print(json.dumps({"rank": rank, "n_mine": out["local_starts"], "cost": out["cost"], "start": out["start"],
+                  "tour_ok": bool((out["tour"] == out["start"]).all()), "ids_ok": calls == [M.shard_starts(len(table), rank, world)]}))
 dist.destroy_process_group()
 '''
 
@@ -157,7 +158,7 @@ def test_multistart_allreduce_world2_gloo(tmp_path):
         outs.append(__import__("json").loads(o.strip().splitlines()[-1]))
     exp = golden("survey_appendix_b.json")["att532"]["multistart256"]
     table = golden("oracle_vectors.json")["att532_multistart256"]
-    want = [(table[exp["best_start"]]["hash"] >> (8 * b)) & 0x7f for b in range(8)]
+    assert table[exp["best_start"]]["opt_true"] == exp["best_true"]
     for o in outs:
         assert (o["cost"], o["start"]) == (exp["best_true"], exp["best_start"])   # 28998 at start 122
-        assert o["n_mine"] == 128 and o["succ"] == want
+        assert o["n_mine"] == 128 and o["tour_ok"] and o["ids_ok"]                # every rank holds the winner's tour

@@ -8,6 +8,7 @@ from helpers import golden, load_instance
 
 pytestmark = pytest.mark.gpu
 APB = golden("survey_appendix_b.json")
+BIG = golden("oracle_vectors_big.json")   # full CPU descents (oracle, minutes): make_golden_big.py
 
 
 @pytest.fixture(scope="module")
@@ -124,3 +125,52 @@ def test_time_limit_stops_with_a_valid_tour_and_status_2(eng, ctx, mode):
     assert rc == eng.TIME_LIMIT_EXCEEDED
     assert O.is_tour(s) and 0 < st["moves"] < (2704 if mode == 0 else 1427)
     assert o == O.succ_cost(xy, wt, s) and o < obj0
+
+
+# ---- full best-improvement descents and the 128-individual population against the committed oracle vectors -----------
+@pytest.mark.parametrize("engine", [1, 3])     # GRID (k_move_recs + k_sweep), CLUSTER (sorted scan, 256 workgroups)
+@pytest.mark.parametrize("name", ["rand5000", "rand10000"])
+def test_best_improvement_full_descent_equals_golden(eng, ctx, name, engine):
+    """alg_2opt_tabu(skip_edge == NULL) from greedy(0) to the local optimum at BASELINE's sizes: final tour, recomputed cost,
+    sweeps, evaluations, moves and reversal length equal the oracle's full CPU descent (rand10000: 1428 sweeps, 23 CPU
+    minutes; SURVEY.md Appendix B left these cells blank), and so do the tours after 1, 10, 100 and 500 sweeps."""
+    g = BIG[name + "_best"]
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([0], dtype=np.int32))
+    assert obj[0] == g["greedy"]["obj"] and O.fnv1a(succ[0]) == g["greedy"]["hash"]
+    tours = eng.Tours(inst, 1)
+    for cp in g["checkpoints"]:
+        tours.upload(succ[0], obj[0])
+        tours.run_engine(eng.BEST, engine=engine, max_steps=cp["sweeps"])
+        s, o, st = tours.download()
+        assert O.fnv1a(s[0]) == cp["hash"] and o[0] == cp["cost"], cp["sweeps"]
+        assert (st[0]["sweeps"], st[0]["moves"], st[0]["evals"]) == (cp["sweeps"], cp["moves"], cp["evals"])
+    tours.upload(succ[0], obj[0])
+    rc, done = tours.run_engine(eng.BEST, engine=engine)
+    s, o, st = tours.download()
+    tours.close(); inst.close()
+    f = g["final"]
+    assert rc == 0 and done and O.fnv1a(s[0]) == f["hash"] and o[0] == f["cost"]
+    assert {k: st[0][k] for k in ("sweeps", "evals", "moves", "reversed")} == f["stats"]
+
+
+def test_population_refinement_config5_all_128_individuals_equal_golden(eng, ctx):
+    """BASELINE configs[4] at full size: 128 random individuals of rand5000 (src/genetic.c:349-364, libc stream seeded
+    with 123), each refined by alg_2opt: per individual the fitness, final cost, tour hash, sweeps, evaluations, moves
+    and reversal length of the oracle's table."""
+    g = BIG["config5_rand5000_pop128"]
+    xy, wt = load_instance("rand5000")
+    O.srandom(g["seed"])
+    perms = np.stack([O.random_perm(g["n"]) for _ in range(g["population"])])
+    succ = np.stack([O.perm_to_succ(p) for p in perms])
+    inst = eng.Instance(ctx, xy, wt, 1)
+    cost = inst.perm_cost(perms)
+    rc, s2, o2, st = inst.two_opt(succ, cost, mode=eng.FIRST)
+    inst.close()
+    assert rc == 0
+    for k, row in enumerate(g["individuals"]):
+        assert O.fnv1a(perms[k]) == row["perm_hash"] and cost[k] == row["fitness"], k
+        assert o2[k] == row["cost"] and O.fnv1a(s2[k]) == row["hash"], k
+        assert (st[k]["sweeps"], st[k]["evals"], st[k]["moves"], st[k]["reversed"]) == \
+            (row["sw"], row["ev"], row["mv"], row["reversed"]), k

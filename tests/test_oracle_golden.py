@@ -167,3 +167,21 @@ def test_best_improvement_with_tabu_skips_and_expires():
     _, s_e, o_e, st_e, tr_e, _ = O.two_opt_best(xy, wt, succ, tabu=tabu, iter_=10, tenure=3,
                                                  max_sweeps=1, trace_cap=4)
     assert tr_e[0][:2] == (i, j) and tabu[O.lib().orc_udir_pos(i, j, n)] == 0
+
+
+def test_big_vectors_are_consistent_with_the_oracle_prefixes():
+    """oracle_vectors_big.json (full descents, minutes of CPU) is not regenerated here; its cheap prefixes are: greedy(0),
+    the tour after 1 and after 10 best-improvement sweeps of rand5000, and the first individuals' fitness of config 5."""
+    big = golden("oracle_vectors_big.json")
+    xy, wt = load_instance("rand5000")
+    _, g, gobj = O.greedy(xy, wt)
+    e = big["rand5000_best"]
+    assert gobj == e["greedy"]["obj"] and O.fnv1a(g) == e["greedy"]["hash"]
+    for cp in e["checkpoints"][:2]:
+        _, s, o, st, _, _ = O.two_opt_best(xy, wt, g, max_sweeps=cp["sweeps"])
+        assert (O.fnv1a(s), o, st["moves"], st["evals"]) == (cp["hash"], cp["cost"], cp["moves"], cp["evals"])
+    c5 = big["config5_rand5000_pop128"]
+    O.srandom(c5["seed"])
+    for row in c5["individuals"][:3]:
+        p = O.random_perm(c5["n"])
+        assert O.fnv1a(p) == row["perm_hash"] and O.perm_cost(xy, wt, p) == row["fitness"]
