@@ -175,7 +175,8 @@ int tsp_dev_tours_reset(tsp_dev_tours *t);
 int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t tour_stride,
                            double *obj, tsp_two_opt_stats *stats);
 /* Run at most max_steps GRID-engine steps (one step = one scan of the selection rule's range and at
- * most one move per tour) in `mode`; max_steps < 0 = until every tour is at its local optimum.
+ * most one move per tour) in `mode`; max_steps < 0 = until every tour is at its local optimum (needs sync != 0:
+ * an unbounded run without polls is refused with TSP_DEV_E_ARG).
  * Does not wait for completion unless `sync` != 0.  *all_done (if not NULL, sync only). */
 int tsp_dev_tours_run(tsp_dev_tours *t, int mode, int64_t max_steps, double time_limit_s, int sync,
                       int *all_done);
@@ -185,6 +186,27 @@ int tsp_dev_tours_run(tsp_dev_tours *t, int mode, int64_t max_steps, double time
  * TSP_ENGINE_AUTO picks CLUSTER where it applies, else GRID. */
 int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s,
                              int *all_done);
+/* ---- drivers on resident tours: what tabu() (src/tabusearch.c:188-320) and HEU_VNS (src/vns.c:103-166) do between two
+ * 2-opt calls, on the device, so that an iteration moves no tour and no stamp across PCIe ------------------------------ */
+/* alg_2opt / alg_2opt_tabu(NULL) on the tours as they are: the cursor starts a new sweep, obj_best continues (FIRST adds its
+ * deltas to the value the control block holds, src/heuristics.c:442,486).  obj[B] (may be NULL) receives the result. */
+int tsp_dev_tours_two_opt(tsp_dev_tours *t, int mode, int engine, double time_limit_s, double *obj);
+/* One alg_2opt_tabu(inst, skip_edge, prev, iter, tenure) on resident tour 0 with resident stamps (B == 1). */
+int tsp_dev_tours_two_opt_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj);
+/* One trial of tabu()'s kick (src/tabusearch.c:262-309) with the host-drawn nodes a, b: rejected if the two edges share a
+ * node or one of (a,a1) (b,b1) (a,b) (a1,b1) is in the tabu list (check_tenure with its lazy clears, in that order); else
+ * the 2-exchange is carried out and (a,a1), (b,b1) are stamped with iter.  *accepted = 1 / 0. */
+int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted);
+/* kick() of src/vns.c:11-100 with the three host-drawn, sorted tour positions p1 < p2 < p3 (positions of the walk from
+ * node 0): segments tour[p1+1..p2] and tour[p2+1..p3] swap places; the recomputed cost (:77-86) goes to the control block
+ * and to *obj (may be NULL). */
+int tsp_dev_tours_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj);
+/* Page-lock / release a caller's host array that is passed to the library again and again (uploads at PCIe speed). */
+int tsp_dev_host_register(void *p, size_t bytes);
+int tsp_dev_host_unregister(void *p);
+/* Incumbent on the device: remember the current tours + costs / go back to them (src/vns.c:148-158, tabusearch.c:241-249). */
+int tsp_dev_tours_snapshot(tsp_dev_tours *t);
+int tsp_dev_tours_restore(tsp_dev_tours *t);
 /* Launch `reps` best-improvement steps back to back on the current tours (they continue the descent)
  * with HIP events around the run on the engine's stream; returns the mean duration of a step's
  * launches in *mean_ms and the reference-equivalent evaluations per step in *evals_per_launch.

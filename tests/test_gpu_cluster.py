@@ -139,3 +139,109 @@ def test_cluster_gives_up_cleanly_when_a_cluster_cannot_be_resident(eng, ctx, mo
     with pytest.raises(eng.TspDeviceError):
         inst.two_opt(succ0, obj0, mode=eng.FIRST, engine=eng.ENGINE_CLUSTER)
     inst.close()
+
+
+# ---- drivers on resident tours: the kicks of tabu() and HEU_VNS on the device --------------------------------------
+def test_resident_tabu_iterations_equal_oracle(eng, ctx):
+    """tabusearch.c:238-309 through the resident-tour API: alg_2opt_tabu on the device-resident tour with device-resident
+    stamps, then the kick as one launch per trial (host-drawn a, b; check_tenure with its lazy clears; 2-exchange; stamps).
+    After 60 iterations the tour, its cost and the whole stamp array equal a host replay with the oracle's alg_2opt_tabu."""
+    xy, wt = load_instance("pr299")
+    n = len(xy)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ0, obj0)
+    tabu = eng.Tabu(inst)
+    stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
+    succ = succ0.copy()
+    rng = np.random.default_rng(11)
+    lo, hi = int(np.ceil(n * 0.02)), int(round(n * 0.1))
+    tenure = lo
+
+    def upos(i, j):
+        i, j = min(i, j), max(i, j)
+        return i * n + j - (i + 1) * (i + 2) // 2
+
+    def is_tabu(idx, it):
+        v = stamps[idx]
+        if v == 0:
+            return False
+        if it - v > tenure:
+            stamps[idx] = 0
+            return False
+        return True
+
+    for it in range(1, 61):
+        rc, obj = tours.two_opt_tabu(tabu, it, tenure)
+        _, succ, eo, _, _, prev = O.two_opt_best(xy, wt, succ, tabu=stamps, iter_=it, tenure=tenure, want_prev=True)
+        assert rc == 0 and obj == eo, it
+        while True:
+            a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+            a1, b1 = int(succ[a]), int(succ[b])
+            acc = tours.tabu_kick(tabu, a, b, it, tenure)
+            if a == b or a1 == b or b1 == a:
+                assert not acc
+                continue
+            free = not is_tabu(upos(a, a1), it) and not is_tabu(upos(b, b1), it) and \
+                not is_tabu(upos(a, b), it) and not is_tabu(upos(a1, b1), it)
+            assert acc == free, (it, a, b)
+            if free:
+                break
+        succ[a] = b; succ[a1] = b1
+        cur = a1                                   # reverse_path(b, a1): the path b .. a1 backwards (utility.c:708-717)
+        nodes = []
+        v = b
+        while True:
+            nodes.append(v)
+            if v == a1:
+                break
+            v = int(prev[v])
+        for x, y in zip(nodes[:-1], nodes[1:]):
+            succ[x] = y
+        succ[a1] = b1
+        stamps[upos(a, a1)] = it; stamps[upos(b, b1)] = it
+        if it % 20 == 0:
+            tenure = hi if tenure == lo else lo
+    s, o, _ = tours.download()
+    assert (s[0] == succ).all()
+    assert (tabu.download() == stamps).all()
+    tabu.close(); tours.close(); inst.close()
+
+
+def test_resident_vns_rounds_equal_oracle(eng, ctx):
+    """vns.c:138-158 through the resident-tour API: kick (segment swap, recomputed cost) and alg_2opt on the device, the
+    incumbent kept / restored device-to-device; 25 rounds equal the oracle's kick + alg_2opt replayed on the host."""
+    xy, wt = load_instance("att532")
+    n = len(xy)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ0, obj0)
+    rc, obj = tours.two_opt(eng.FIRST)
+    _, best, best_obj, _, _ = O.two_opt_first(xy, wt, succ0, obj0)
+    assert obj[0] == best_obj
+    tours.snapshot()
+    rng = np.random.default_rng(4)
+    for r in range(25):
+        p = sorted(rng.choice(n, size=3, replace=False).tolist())
+        if p[1] - p[0] <= 1 or p[2] - p[1] <= 1:
+            continue
+        kobj = tours.vns_kick(p[0], p[1], p[2])
+        tour = O.succ_to_perm(best)
+        a, b, c, d, e = tour[p[0]], tour[p[0] + 1], tour[p[1]], tour[p[1] + 1], tour[p[2]]
+        f = tour[(p[2] + 1) % n]
+        cand = best.copy()
+        cand[a] = d; cand[e] = b; cand[c] = f
+        assert O.is_tour(cand) and kobj == O.succ_cost(xy, wt, cand), r
+        rc, obj = tours.two_opt(eng.FIRST)
+        _, es, eo, _, _ = O.two_opt_first(xy, wt, cand, kobj)
+        assert obj[0] == eo, r
+        if eo < best_obj:
+            best, best_obj = es, eo
+            tours.snapshot()
+        else:
+            tours.restore()
+    s, o, _ = tours.download()
+    assert (s[0] == best).all() and o[0] == best_obj
+    tours.close(); inst.close()

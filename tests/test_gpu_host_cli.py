@@ -321,3 +321,46 @@ def test_cli_method_prefix_cascade_and_tour_file(tmp_path):
     assert tour[0] == "NAME : att532.tour" and tour[3] == "OBJECTIVE : 30594.000000"
     nodes = [int(x) for x in tour[6:6 + 532]]
     assert sorted(nodes) == list(range(1, 533)) and tour[6 + 532] == "-1"
+
+
+# ---- reentrancy: the one multi-threaded caller of alg_2opt in the reference (CPLEX callbacks, callback.c:64-69) -------
+def test_alg_2opt_from_four_threads_on_private_copies(host):
+    """callback.c:64-69: every CPLEX thread polishes its candidate with alg_2opt on a private copy_instance.  Four threads
+    call alg_2opt concurrently on private copies of pr299 with different tours (the shim serialises device access behind one
+    mutex); every result must equal the single-threaded oracle run of the same tour."""
+    import threading
+    host.copy_instance.argtypes = [C.POINTER(Instance), C.POINTER(Instance)]
+    host.free_instance.argtypes = [C.POINTER(Instance)]
+    base = HostInstance("pr299")
+    _, s0, o0 = O.greedy(base.xy, base.wt)
+    base.set_tour(s0, o0)
+    rng = np.random.default_rng(3)
+    starts = []
+    for k in range(4):
+        if k == 0:
+            starts.append((s0.copy(), o0))
+        else:
+            perm = rng.permutation(base.n).astype(np.int32)
+            succ = np.empty(base.n, dtype=np.int32); succ[perm] = np.roll(perm, -1)
+            starts.append((succ, O.succ_cost(base.xy, base.wt, succ)))
+    copies = [Instance() for _ in range(4)]
+    results = [None] * 4
+
+    def work(k):
+        host.copy_instance(C.byref(copies[k]), C.byref(base.c))     # deep copy of nodes and edges (utility.c:724-743)
+        e = copies[k].solution.edges
+        for v in range(base.n):
+            e[v].i = v; e[v].j = int(starts[k][0][v])
+        copies[k].solution.obj_best = starts[k][1]
+        for _ in range(3):                                          # several calls per thread, interleaved with the others
+            rc = host.alg_2opt(C.byref(copies[k]))
+            assert rc == 0
+        results[k] = (np.array([e[v].j for v in range(base.n)], dtype=np.int32), copies[k].solution.obj_best)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for k in range(4):
+        _, es, eo, _, _ = O.two_opt_first(base.xy, base.wt, starts[k][0], starts[k][1])
+        assert results[k] is not None and (results[k][0] == es).all() and results[k][1] == eo, k
+        host.free_instance(C.byref(copies[k]))

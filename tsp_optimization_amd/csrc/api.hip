@@ -19,6 +19,19 @@ bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode);
 int tsp_cluster_size(const tsp_dev_tours *t, int mode);
 int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through);
 
+void *tsp_io_pool(tsp_dev_inst *inst, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > inst->io_pool_bytes) {
+        (void)hipStreamSynchronize(inst->ctx->stream);   // nobody may still be using the old block
+        (void)hipFree(inst->io_pool);
+        inst->io_pool = nullptr; inst->io_pool_bytes = 0;
+        const size_t want = std::max(bytes, (size_t)1 << 16);
+        if (hipMalloc(&inst->io_pool, want) != hipSuccess) { inst->io_pool = nullptr; return nullptr; }
+        inst->io_pool_bytes = want;
+    }
+    return inst->io_pool;
+}
+
 namespace tsp {
 static thread_local char g_last_error[512] = "";
 void set_last_error(const char *what, hipError_t e, const char *file, int line) {
@@ -85,8 +98,9 @@ __global__ void k_raw_sqrt(const double *__restrict__ in, int count, double *__r
 // costs are not integer-valued.
 template <int WT, bool INT>
 __global__ __launch_bounds__(256) void k_perm_cost(const double2 *__restrict__ coord, const int *__restrict__ perm,
-                                                   long long perm_stride, int n, double *__restrict__ cost) {
+                                                   long long perm_stride, int n, double *cost, size_t cost_stride_bytes) {
     const int *p = perm + (size_t)blockIdx.x * perm_stride;
+    double *out = reinterpret_cast<double *>(reinterpret_cast<char *>(cost) + blockIdx.x * cost_stride_bytes);
     __shared__ double s_part[256];
     __shared__ double s_chunk[2048];
     const int tid = threadIdx.x;
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void k_perm_cost(const double2 *__restrict__ c
             if (tid < s) s_part[tid] += s_part[tid + s];
             __syncthreads();
         }
-        if (tid == 0) cost[blockIdx.x] = s_part[0];
+        if (tid == 0) *out = s_part[0];
     } else {
         double acc = 0.0;
         for (int base = 0; base < n; base += 2048) {
@@ -118,12 +132,30 @@ __global__ __launch_bounds__(256) void k_perm_cost(const double2 *__restrict__ c
                 for (int t = 0; t < m; ++t) acc += s_chunk[t];
             }
         }
-        if (tid == 0) cost[blockIdx.x] = acc;
+        if (tid == 0) *out = acc;
     }
 }
 }  // namespace
 
 using tsp::DevBuf;
+
+// fitness() of B permutations that already sit on the device (src/genetic.c:51-60); out[b] at out_stride_bytes
+int tsp_perm_cost_device(tsp_dev_inst *inst, const int *d_perm, long long stride, int B, double *d_out, size_t out_stride_bytes) {
+    hipStream_t s = inst->ctx->stream;
+    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
+        hipLaunchKernelGGL((k_perm_cost<WTC, INTC>), dim3(B), dim3(256), 0, s, inst->d_coord, d_perm, stride, inst->n, d_out,
+                           out_stride_bytes);
+    });
+    TSP_HIP_TRY(hipGetLastError());
+    return TSP_OK;
+}
+
+// two_opt_grid.hip: drivers on resident tours
+int tsp_grid_rearm(tsp_dev_tours *t, int mode);
+int tsp_grid_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted);
+int tsp_grid_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj);
+int tsp_grid_snapshot(tsp_dev_tours *t, bool restore);
+int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj);
 
 extern "C" {
 
@@ -145,12 +177,14 @@ int tsp_dev_open(int device, tsp_dev_ctx **out) {
     }
     if (hipSetDevice(device) != hipSuccess) return TSP_DEV_E_NODEVICE;
     tsp_dev_ctx *c = new tsp_dev_ctx();
+    struct Guard { tsp_dev_ctx *c; ~Guard() { delete c; } } guard{c};   // an early error return frees the context
     c->device = device;
     hipDeviceProp_t prop;
     TSP_HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
     c->lds_bytes = (int)prop.sharedMemPerBlock;
     TSP_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    guard.c = nullptr;
     *out = c;
     return TSP_OK;
 }
@@ -188,7 +222,8 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
         double lox = xy[0], hix = xy[0], loy = xy[1], hiy = xy[1];
         for (int v = 0; v < n; ++v) {
             const double x = xy[2 * v], y = xy[2 * v + 1];
-            all_int = all_int && x == (double)(long long)x && y == (double)(long long)y && fabs(x) < 4.0e15 && fabs(y) < 4.0e15;
+            if (!std::isfinite(x) || !std::isfinite(y)) return TSP_DEV_E_ARG;   // NaN / inf coordinates: nothing downstream is defined
+            all_int = all_int && fabs(x) < 4.0e15 && fabs(y) < 4.0e15 && x == (double)(long long)x && y == (double)(long long)y;
             lox = x < lox ? x : lox; hix = x > hix ? x : hix; loy = y < loy ? y : loy; hiy = y > hiy ? y : hiy;
         }
         const double span = sqrt((hix - lox) * (hix - lox) + (hiy - loy) * (hiy - loy));
@@ -275,7 +310,7 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
     if (inst->scratch_b) tsp_dev_tours_destroy(inst->scratch_b);
     if (inst->ev0) { (void)hipEventDestroy(inst->ev0); (void)hipEventDestroy(inst->ev1); }
     (void)hipFree(inst->d_coord); (void)hipFree(inst->d_sperm); (void)hipFree(inst->d_gbox); (void)hipFree(inst->d_sxy); (void)hipFree(inst->cons_pool);
-    (void)hipFree(inst->d_rcoord); (void)hipFree(inst->d_sinv);
+    (void)hipFree(inst->d_rcoord); (void)hipFree(inst->d_sinv); (void)hipFree(inst->io_pool);
     delete inst;
 }
 
@@ -288,11 +323,11 @@ int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count
         if (i[k] < 0 || i[k] >= inst->n || j[k] < 0 || j[k] >= inst->n) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    DevBuf<int> d_i, d_j;
-    DevBuf<double> d_o;
-    TSP_HIP_TRY(d_i.alloc((size_t)count));
-    TSP_HIP_TRY(d_j.alloc((size_t)count));
-    TSP_HIP_TRY(d_o.alloc((size_t)count));
+    // one block of the instance's scratch: out | i | j
+    char *pool = static_cast<char *>(tsp_io_pool(inst, (size_t)count * 16));
+    if (!pool) return TSP_DEV_E_NOMEM;
+    double *d_o = reinterpret_cast<double *>(pool);
+    int *d_i = reinterpret_cast<int *>(pool + (size_t)count * 8), *d_j = d_i + count;
     TSP_HIP_TRY(hipMemcpyAsync(d_i, i, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     TSP_HIP_TRY(hipMemcpyAsync(d_j, j, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
@@ -329,16 +364,14 @@ int tsp_dev_perm_cost(tsp_dev_inst *inst, int B, const int *perm, int64_t perm_s
         }
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     hipStream_t s = inst->ctx->stream;
-    DevBuf<int> d_p;
-    DevBuf<double> d_c;
     const size_t words = (size_t)(B - 1) * perm_stride + n;
-    TSP_HIP_TRY(d_p.alloc(words));
-    TSP_HIP_TRY(d_c.alloc((size_t)B));
+    char *pool = static_cast<char *>(tsp_io_pool(inst, (size_t)B * 8 + words * 4));   // cost | permutations
+    if (!pool) return TSP_DEV_E_NOMEM;
+    double *d_c = reinterpret_cast<double *>(pool);
+    int *d_p = reinterpret_cast<int *>(pool + (size_t)B * 8);
     TSP_HIP_TRY(hipMemcpyAsync(d_p, perm, sizeof(int) * words, hipMemcpyHostToDevice, s));
-    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
-        hipLaunchKernelGGL((k_perm_cost<WTC, INTC>), dim3(B), dim3(256), 0, s, inst->d_coord, d_p,
-                           (long long)perm_stride, n, d_c);
-    });
+    int rc = tsp_perm_cost_device(inst, d_p, (long long)perm_stride, B, d_c, sizeof(double));
+    if (rc) return rc;
     TSP_HIP_TRY(hipMemcpyAsync(cost, d_c, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
@@ -460,6 +493,66 @@ int tsp_dev_tours_run_engine(tsp_dev_tours *t, int mode, int engine, int64_t max
     TSP_HIP_TRY(hipEventElapsedTime(&ms, inst->ev0, inst->ev1));
     t->device_ms = ms;
     return status;
+}
+
+// ---- drivers on resident tours: tabu() and HEU_VNS keep the tour (and the stamps) on the device between their steps ----
+
+int tsp_dev_tours_two_opt(tsp_dev_tours *t, int mode, int engine, double time_limit_s, double *obj) {
+    if (!t || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    int rc = tsp_grid_rearm(t, mode);
+    if (rc) return rc;
+    int done = 0;
+    const int status = tsp_dev_tours_run_engine(t, mode, engine, -1, time_limit_s, &done);
+    if (status < 0) return status;
+    hipStream_t s = t->inst->ctx->stream;
+    TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(tsp::TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    if (obj) for (int b = 0; b < t->B; ++b) obj[b] = t->h_state[b].obj;
+    return status;
+}
+
+int tsp_dev_tours_two_opt_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_resident_tabu(t, tabu, iter, tenure, time_limit_s, obj);
+}
+
+int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_tabu_kick(t, tabu, a, b, iter, tenure, accepted);
+}
+
+int tsp_dev_tours_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_vns_kick(t, p1, p2, p3, obj);
+}
+
+/* Page-locks a caller's host array so that the uploads / downloads of a loop that passes the same array again and again
+ * (alg_2opt_tabu's skip_edge: 4 n^2 / 2 bytes each way per call) run at PCIe speed. */
+int tsp_dev_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return TSP_OK;
+}
+int tsp_dev_host_unregister(void *p) {
+    if (!p) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipHostUnregister(p));
+    return TSP_OK;
+}
+
+int tsp_dev_tours_snapshot(tsp_dev_tours *t) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_snapshot(t, false);
+}
+
+int tsp_dev_tours_restore(tsp_dev_tours *t) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_snapshot(t, true);
 }
 
 }  // extern "C"

@@ -81,6 +81,8 @@ struct tsp_dev_inst {
     double org_x = 0.0, org_y = 0.0;   // min corner of the coordinates
     double cost_bound = 1e300;         // no distance of the instance exceeds this (bounding-box diagonal + rounding)
     std::vector<int> h_sinv;           // node -> rank slot
+    void *io_pool = nullptr;           // call-local device scratch of the small host-array entry points (fitness, spot
+    size_t io_pool_bytes = 0;          // distances, stamp reads/writes), grown on demand: no hipMalloc per call
     void *cons_pool = nullptr;         // scratch of tsp_dev_construct, grown on demand
     size_t cons_pool_bytes = 0;
     void *d_sxy = nullptr;             // coordinates in rank order (float2 / double2), built on first use by the large greedy
@@ -126,6 +128,11 @@ struct tsp_dev_tours {
     int cl_C = 0;
     int *d_cl_pairtab = nullptr;
     int cl_ntests = 0;
+    // drivers on resident tours: the incumbent kept on the device (tsp_dev_tours_snapshot / _restore), kick results
+    int *d_order_snap = nullptr;
+    std::vector<double> h_obj_snap;
+    int *d_kick_result = nullptr;
+    int *h_kick_result = nullptr;    // pinned
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;
     std::vector<double> h_obj0;
@@ -165,6 +172,9 @@ struct DevBuf {
     operator T *() const { return p; }
 };
 }
+// Per-instance scratch for the host-array entry points (not for concurrent use, like every handle): >= bytes, 256-aligned.
+void *tsp_io_pool(tsp_dev_inst *inst, size_t bytes);
+
 #define TSP_HIP_TRY(expr)                                                    \
     do {                                                                     \
         hipError_t e__ = (expr);                                             \

@@ -46,6 +46,74 @@ __global__ void k_stamp_gather(const int *__restrict__ stamp, const int *__restr
     if (t < count) val[t] = stamp[idx[t]];
 }
 
+
+// ---- drivers on resident tours: the state stays on the device between the steps of tabu() / HEU_VNS ----
+
+// A new alg_2opt / alg_2opt_tabu call on the tour that is already there: cursor at the start of a sweep, obj_best as it
+// stands (FIRST adds deltas to it, heuristics.c:442), nothing pending.  The executed-work and sweep counters run on.
+__global__ void k_rearm(TourState *states, int B, int first_chunk) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    TourState *st = states + b;
+    st->ci = 0; st->cj = 0; st->chunk_rows = first_chunk; st->done = 0;
+    st->seen_cost = st->obj;
+    st->parity = 0; st->pending = 0;
+}
+
+// One trial of tabu()'s kick (src/tabusearch.c:262-295) on tour 0 of the handle: the host has drawn a and b.  Rejected
+// without touching the stamps when the edges share a node (:271-273); else the four check_tenure calls of the && chain in
+// the reference's order, lazy clears included (:83-92, :282-285); if every edge is free the 2-exchange is carried out
+// (edges[a].j = b, edges[a1].j = b1, reverse_path(b, a1): positions pos[a]+1 .. pos[b] reversed) and the two removed edges
+// are stamped with iter (:306-309 -- the policy update in between does not read them).  result = {accepted, a1, b1, 0}.
+__global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *pos, int *stamp, int n, int a, int b, int iter,
+                                                             int tenure, int *result) {
+    __shared__ int s_acc, s_pa, s_pb;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int pa = pos[a], pb = pos[b];
+        const int a1 = order[pa + 1 == n ? 0 : pa + 1], b1 = order[pb + 1 == n ? 0 : pb + 1];
+        int acc = 0;
+        if (!(a == b || a1 == b || b1 == a)) {
+            acc = !stamp_is_tabu(stamp + udir_pos(a, a1, n), iter, tenure) && !stamp_is_tabu(stamp + udir_pos(b, b1, n), iter, tenure) &&
+                  !stamp_is_tabu(stamp + udir_pos(a, b, n), iter, tenure) && !stamp_is_tabu(stamp + udir_pos(a1, b1, n), iter, tenure);
+            if (acc) { stamp[udir_pos(a, a1, n)] = iter; stamp[udir_pos(b, b1, n)] = iter; }
+        }
+        result[0] = acc; result[1] = a1; result[2] = b1; result[3] = 0;
+        s_acc = acc; s_pa = pa; s_pb = pb;
+    }
+    __syncthreads();
+    if (!s_acc) return;
+    const int pa = s_pa, pb = s_pb;
+    int L = pb - pa; if (L < 0) L += n;
+    for (int t = tid; t < (L >> 1); t += kApplyThreads) {
+        int p = pa + 1 + t; if (p >= n) p -= n;
+        int q = pb - t; if (q < 0) q += n;
+        const int u = order[p], w = order[q];
+        order[p] = w; order[q] = u;
+        pos[w] = p; pos[u] = q;
+    }
+}
+
+// HEU_VNS's kick (src/vns.c:11-100) on tour 0: with tour[] the walk from node 0, positions p1 < p2 < p3 (host draws),
+// the new tour is tour[0..p1] tour[p2+1..p3] tour[p1+1..p2] tour[p3+1..n-1] (:60-62: a->d, e->b, c->f; the reference reads
+// tour[n] for f when p3 == n-1, here the walk closes on tour[0]).  Out of place into the second copy, node 0 at position 0.
+__global__ void k_vns_kick(const int *__restrict__ order, const int *__restrict__ pos, int *__restrict__ order2,
+                           int *__restrict__ pos2, int n, int p1, int p2, int p3) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int z = pos[0];
+    const int len2 = p3 - p2, len1 = p2 - p1;
+    int src;
+    if (k <= p1) src = k;
+    else if (k <= p1 + len2) src = p2 + 1 + (k - p1 - 1);
+    else if (k <= p1 + len2 + len1) src = p1 + 1 + (k - p1 - len2 - 1);
+    else src = k;
+    int q = z + src; if (q >= n) q -= n;
+    const int v = order[q];
+    order2[k] = v;
+    pos2[v] = k;
+}
+
 }  // namespace tsp
 
 // =============================================================================================
@@ -210,6 +278,7 @@ int env_int(const char *name, int dflt) {
 int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure, int64_t max_steps,
                  double time_limit_s, int sync, int *all_done) {
     if (!t || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
+    if (!sync && max_steps < 0) return TSP_DEV_E_ARG;   // "until done" needs the polls of a synchronous run: it would queue launches forever
     hipStream_t s = t->inst->ctx->stream;
     const double t0 = wall_s();
     const int64_t batch = 64;
@@ -285,6 +354,96 @@ int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
 }
 
 tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc);   // api.hip
+int tsp_perm_cost_device(tsp_dev_inst *inst, const int *d_perm, long long stride, int B, double *d_out, size_t out_stride_bytes);   // api.hip
+
+// ---- resident-tour drivers (called by the extern "C" wrappers in api.hip) ---------------------------------------
+int tsp_grid_rearm(tsp_dev_tours *t, int mode) {
+    hipStream_t s = t->inst->ctx->stream;
+    const int chunk = std::min(t->first_min_rows, std::max(1, t->n - 1));
+    hipLaunchKernelGGL(k_rearm, dim3((t->B + 255) / 256), dim3(256), 0, s, t->d_state, t->B, chunk);
+    (void)mode;
+    TSP_HIP_TRY(hipGetLastError());
+    return TSP_OK;
+}
+
+static int kick_buffers(tsp_dev_tours *t) {
+    if (!t->d_kick_result) {
+        TSP_HIP_TRY(hipMalloc(&t->d_kick_result, 4 * sizeof(int)));
+        TSP_HIP_TRY(hipHostMalloc(&t->h_kick_result, 4 * sizeof(int)));
+    }
+    return TSP_OK;
+}
+
+int tsp_grid_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted) {
+    if (!t || !tabu || t->B != 1 || a < 0 || b < 0 || a >= t->n || b >= t->n) return TSP_DEV_E_ARG;
+    int rc = kick_buffers(t);
+    if (rc) return rc;
+    hipStream_t s = t->inst->ctx->stream;
+    hipLaunchKernelGGL(k_tabu_kick, dim3(1), dim3(kApplyThreads), 0, s, t->d_order, t->d_pos, tabu->d_stamp, t->n, a, b, iter,
+                       tenure, t->d_kick_result);
+    TSP_HIP_TRY(hipMemcpyAsync(t->h_kick_result, t->d_kick_result, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    if (accepted) *accepted = t->h_kick_result[0];
+    return TSP_OK;
+}
+
+int tsp_grid_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj) {
+    if (!t || t->B != 1 || !(0 <= p1 && p1 < p2 && p2 < p3 && p3 < t->n)) return TSP_DEV_E_ARG;
+    hipStream_t s = t->inst->ctx->stream;
+    const int n = t->n;
+    hipLaunchKernelGGL(k_vns_kick, dim3((n + 255) / 256), dim3(256), 0, s, t->d_order, t->d_pos, t->d_order2, t->d_pos2, n, p1, p2, p3);
+    TSP_HIP_TRY(hipMemcpyAsync(t->d_order, t->d_order2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    TSP_HIP_TRY(hipMemcpyAsync(t->d_pos, t->d_pos2, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    // the reference recomputes the cost edge by edge along the new tour from node 0 (vns.c:77-86): order[] IS that walk now
+    int rc = tsp_perm_cost_device(t->inst, t->d_order, n, 1, &t->d_state[0].obj, sizeof(TourState));
+    if (rc) return rc;
+    if (obj) {
+        TSP_HIP_TRY(hipMemcpyAsync(&t->h_state[0].obj, &t->d_state[0].obj, sizeof(double), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        *obj = t->h_state[0].obj;
+    }
+    TSP_HIP_TRY(hipGetLastError());
+    return TSP_OK;
+}
+
+int tsp_grid_snapshot(tsp_dev_tours *t, bool restore) {
+    if (!t) return TSP_DEV_E_ARG;
+    hipStream_t s = t->inst->ctx->stream;
+    const size_t bn = (size_t)t->B * t->n;
+    if (!restore) {
+        if (!t->d_order_snap) TSP_HIP_TRY(hipMalloc(&t->d_order_snap, bn * sizeof(int)));
+        TSP_HIP_TRY(hipMemcpyAsync(t->d_order_snap, t->d_order, bn * sizeof(int), hipMemcpyDeviceToDevice, s));
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        t->h_obj_snap.resize((size_t)t->B);
+        for (int b = 0; b < t->B; ++b) t->h_obj_snap[b] = t->h_state[b].obj;
+        return TSP_OK;
+    }
+    if (!t->d_order_snap || (int)t->h_obj_snap.size() != t->B) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipMemcpyAsync(t->d_order, t->d_order_snap, bn * sizeof(int), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_build_pos, dim3((t->n + 255) / 256, t->B), dim3(256), 0, s, t->d_order, t->d_pos, t->n);
+    for (int b = 0; b < t->B; ++b)
+        TSP_HIP_TRY(hipMemcpyAsync(&t->d_state[b].obj, &t->h_obj_snap[b], sizeof(double), hipMemcpyHostToDevice, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    return TSP_OK;
+}
+
+// alg_2opt_tabu on the resident tour 0 (no upload, no download): *obj = the recomputed cost (tabusearch.c:168-172)
+int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj) {
+    if (!t || t->B != 1 || (tabu && tabu->inst != t->inst)) return TSP_DEV_E_ARG;
+    int rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
+    if (rc) return rc;
+    int done = 0;
+    const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 1, &done);
+    if (status < 0) return status;
+    hipStream_t s = t->inst->ctx->stream;
+    TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    if (obj) *obj = t->h_state[0].obj;
+    return status;
+}
 
 extern "C" {
 
@@ -398,6 +557,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab);
+    (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
     delete t;
@@ -523,12 +683,11 @@ int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed) {
     hipStream_t s = t->inst->ctx->stream;
     std::vector<double> cost((size_t)t->B);
     if (true_cost) {
-        double *d_c = nullptr;
-        TSP_HIP_TRY(hipMalloc(&d_c, sizeof(double) * (size_t)t->B));
+        double *d_c = static_cast<double *>(tsp_io_pool(t->inst, sizeof(double) * (size_t)t->B));
+        if (!d_c) return TSP_DEV_E_NOMEM;
         launch_tour_cost(t, d_c, sizeof(double));
         TSP_HIP_TRY(hipMemcpyAsync(cost.data(), d_c, sizeof(double) * (size_t)t->B, hipMemcpyDeviceToHost, s));
         TSP_HIP_TRY(hipStreamSynchronize(s));
-        (void)hipFree(d_c);
     } else {
         TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
         TSP_HIP_TRY(hipStreamSynchronize(s));
@@ -573,9 +732,8 @@ static int stamp_io(tsp_dev_tabu *tb, const int *idx, int *val, int count, bool 
         if (idx[k] < 0 || idx[k] >= tb->count) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(tb->inst->ctx->device));
     hipStream_t s = tb->inst->ctx->stream;
-    int *d_idx = nullptr, *d_val = nullptr;
-    TSP_HIP_TRY(hipMalloc(&d_idx, sizeof(int) * (size_t)count));
-    TSP_HIP_TRY(hipMalloc(&d_val, sizeof(int) * (size_t)count));
+    int *d_idx = static_cast<int *>(tsp_io_pool(tb->inst, sizeof(int) * 2 * (size_t)count)), *d_val = d_idx + count;
+    if (!d_idx) return TSP_DEV_E_NOMEM;
     TSP_HIP_TRY(hipMemcpyAsync(d_idx, idx, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     if (scatter) {
         TSP_HIP_TRY(hipMemcpyAsync(d_val, val, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
@@ -586,7 +744,6 @@ static int stamp_io(tsp_dev_tabu *tb, const int *idx, int *val, int count, bool 
     }
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
-    (void)hipFree(d_idx); (void)hipFree(d_val);
     return TSP_OK;
 }
 

@@ -77,6 +77,12 @@ def lib():
         L.tsp_dev_tours_download.argtypes = [vp, ip, C.c_int, C.c_int64, dp, sp]
         L.tsp_dev_tours_run.argtypes = [vp, C.c_int, C.c_int64, C.c_double, C.c_int, ip]
         L.tsp_dev_tours_run_engine.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_double, ip]
+        L.tsp_dev_tours_two_opt.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp]
+        L.tsp_dev_tours_two_opt_tabu.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, dp]
+        L.tsp_dev_tours_tabu_kick.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ip]
+        L.tsp_dev_tours_vns_kick.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+        L.tsp_dev_tours_snapshot.argtypes = [vp]
+        L.tsp_dev_tours_restore.argtypes = [vp]
         L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
         _lib = L
@@ -91,6 +97,8 @@ EXPORTED = [
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
+    "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_vns_kick",
+    "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
 ]
 
 
@@ -302,7 +310,9 @@ class Tours:
         _check(lib().tsp_dev_tours_reset(self._h))
 
     def run(self, mode, max_steps=-1, time_limit=-1.0, sync=True):
-        """-> (status, all_done)"""
+        """-> (status, all_done).  max_steps < 0 (until done) needs sync=True."""
+        if not sync and max_steps < 0:
+            raise ValueError("an unbounded run needs sync=True (it is driven by polls of the done flags)")
         done = C.c_int(0)
         rc = lib().tsp_dev_tours_run(self._h, mode, max_steps, time_limit, 1 if sync else 0, C.byref(done))
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
@@ -314,6 +324,36 @@ class Tours:
         rc = lib().tsp_dev_tours_run_engine(self._h, mode, engine, max_steps, time_limit, C.byref(done))
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
         return rc, bool(done.value)
+
+    # -- drivers on resident tours -------------------------------------------------------------
+    def two_opt(self, mode, engine=ENGINE_AUTO, time_limit=-1.0):
+        """alg_2opt / alg_2opt_tabu(NULL) on the tours as they are -> (status, obj [B])"""
+        obj = np.zeros(self.B, dtype=np.float64)
+        rc = lib().tsp_dev_tours_two_opt(self._h, mode, engine, time_limit, _d(obj))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, obj
+
+    def two_opt_tabu(self, tabu, iter_, tenure, time_limit=-1.0):
+        obj = C.c_double(0)
+        rc = lib().tsp_dev_tours_two_opt_tabu(self._h, tabu._h if tabu is not None else None, iter_, tenure, time_limit, C.byref(obj))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, obj.value
+
+    def tabu_kick(self, tabu, a, b, iter_, tenure):
+        acc = C.c_int(0)
+        _check(lib().tsp_dev_tours_tabu_kick(self._h, tabu._h, a, b, iter_, tenure, C.byref(acc)))
+        return bool(acc.value)
+
+    def vns_kick(self, p1, p2, p3):
+        obj = C.c_double(0)
+        _check(lib().tsp_dev_tours_vns_kick(self._h, p1, p2, p3, C.byref(obj)))
+        return obj.value
+
+    def snapshot(self):
+        _check(lib().tsp_dev_tours_snapshot(self._h))
+
+    def restore(self):
+        _check(lib().tsp_dev_tours_restore(self._h))
 
     def download(self):
         """-> (succ [B,n], obj [B], [stats])"""

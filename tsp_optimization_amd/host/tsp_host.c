@@ -35,6 +35,15 @@ typedef struct {
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static tsp_dev_ctx *g_ctx = NULL;
 static cache_slot g_cache[CACHE_SLOTS];
+/* device copy of the skip_edge array a caller keeps passing to alg_2opt_tabu (see there) */
+static struct { int *host; tsp_dev_inst *dev; tsp_dev_tabu *tb; size_t bytes; int registered; } g_tabu_cache;
+
+static void tabu_cache_drop(void) {
+    if (g_tabu_cache.tb) tsp_dev_tabu_destroy(g_tabu_cache.tb);
+    if (g_tabu_cache.registered) (void)tsp_dev_host_unregister(g_tabu_cache.host);
+    memset(&g_tabu_cache, 0, sizeof g_tabu_cache);
+}
+
 static unsigned long g_clock = 0;
 static __thread long long t_sweeps, t_evals, t_moves;
 static __thread double t_device_ms;
@@ -76,6 +85,7 @@ static tsp_dev_inst *dev_inst_locked(instance *inst) {
         if (g_cache[k].stamp < g_cache[victim].stamp) victim = k;
     }
     cache_slot *c = &g_cache[victim];
+    if (c->dev && g_tabu_cache.dev == c->dev) tabu_cache_drop();
     if (c->dev) tsp_dev_inst_destroy(c->dev);
     memset(c, 0, sizeof *c);
     int rc = tsp_dev_inst_create(ctx_locked(), (const double *)inst->nodes, inst->num_nodes, (int)inst->weight_type, ic,
@@ -88,6 +98,7 @@ static tsp_dev_inst *dev_inst_locked(instance *inst) {
 
 void tsp_host_shutdown(void) {
     pthread_mutex_lock(&g_lock);
+    tabu_cache_drop();
     for (int k = 0; k < CACHE_SLOTS; k++)
         if (g_cache[k].dev) { tsp_dev_inst_destroy(g_cache[k].dev); memset(&g_cache[k], 0, sizeof g_cache[k]); }
     if (g_ctx) { tsp_dev_close(g_ctx); g_ctx = NULL; }
@@ -294,9 +305,11 @@ int alg_2opt(instance *inst) {
     return rc;
 }
 
-/* src/tabusearch.c:107-178.  skip_edge is the caller's host array of n(n-1)/2 stamps, so it is
- * moved to the device and back around the call (callers that keep the stamps resident use
- * tsp_dev_two_opt_tabu directly). */
+/* src/tabusearch.c:107-178.  skip_edge is the caller's host array of n(n-1)/2 stamps, which the caller also writes
+ * between two calls (tabu() stamps two edges per iteration, check_tenure clears lazily), so it has to travel to the device
+ * and back around every call.  What a loop like the reference's tabu() does not pay again and again: the device copy (one
+ * handle per skip_edge pointer, kept until another pointer or instance comes) and pageable-memory copies (the array is
+ * page-locked once).  A driver that wants no copies at all keeps the stamps resident: tsp_host_tabu / HEU_Tabu_* below. */
 int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int iter, const int tenure) {
     tsp_two_opt_stats st;
     memset(&st, 0, sizeof st);
@@ -306,15 +319,21 @@ int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int it
     tsp_dev_tabu *tb = NULL;
     int rc = 0;
     if (skip_edge) {
-        rc = tsp_dev_tabu_create(d, &tb);
+        if (g_tabu_cache.tb && (g_tabu_cache.host != skip_edge || g_tabu_cache.dev != d)) tabu_cache_drop();
+        if (!g_tabu_cache.tb) {
+            rc = tsp_dev_tabu_create(d, &g_tabu_cache.tb);
+            if (!rc) {
+                g_tabu_cache.host = skip_edge; g_tabu_cache.dev = d;
+                g_tabu_cache.bytes = sizeof(int) * (size_t)inst->num_nodes * (size_t)(inst->num_nodes - 1) / 2;
+                g_tabu_cache.registered = tsp_dev_host_register(skip_edge, g_tabu_cache.bytes) == 0;   /* best effort */
+            }
+        }
+        tb = g_tabu_cache.tb;
         if (!rc) rc = tsp_dev_tabu_upload(tb, skip_edge);
     }
     if (!rc) rc = tsp_dev_two_opt_tabu(d, tb, iter, tenure, &inst->solution.edges[0].j, 2, &obj, stored_prev,
                                        limit_of(inst), &st);
-    if (tb) {
-        if (rc >= 0) { int rc2 = tsp_dev_tabu_download(tb, skip_edge); if (rc2) rc = rc2; }
-        tsp_dev_tabu_destroy(tb);
-    }
+    if (tb && rc >= 0) { int rc2 = tsp_dev_tabu_download(tb, skip_edge); if (rc2) rc = rc2; }
     pthread_mutex_unlock(&g_lock);
     if (rc < 0) dev_fail("tsp_dev_two_opt_tabu", rc);
     inst->solution.obj_best = obj;
@@ -360,7 +379,29 @@ int kick(instance *inst) {
     return 0;
 }
 
-/* vns.c:103-166 */
+/* The three tour positions of kick() (vns.c:23-47), drawn and sorted on the host: the draws are the reference's. */
+static void kick_positions(int n, int *p1, int *p2, int *p3) {
+    int a = rand_choice(0, n), b = a, c = a;
+    while (b == a || abs(a - b) <= 1) b = rand_choice(0, n);
+    while (c == a || c == b || abs(a - c) <= 1 || abs(b - c) <= 1) c = rand_choice(0, n);
+    int t;
+    if (a > b) { t = a; a = b; b = t; }
+    if (a > c) { t = a; a = c; c = t; }
+    if (b > c) { t = b; b = c; c = t; }
+    *p1 = a; *p2 = b; *p3 = c;
+}
+
+static void download_into(instance *inst, tsp_dev_tours *t) {
+    double obj = 0.0;
+    int rc = tsp_dev_tours_download(t, &inst->solution.edges[0].j, 2, 2 * (int64_t)inst->num_nodes, &obj, NULL);
+    if (rc) dev_fail("tsp_dev_tours_download", rc);
+    stamp_edge_sources(inst);
+    inst->solution.obj_best = obj;
+}
+
+/* vns.c:103-166.  After the initial solution the tour lives on the device: a round is kick (segment swap + recomputed
+ * cost, one kernel each), alg_2opt on the resident tour, one 8-byte read of the cost, and a device-to-device copy that
+ * either remembers the new incumbent or goes back to the old one (:148-158).  Only the draws are host work. */
 int tsp_host_vns(instance *inst, long long max_rounds) {
     const int n = inst->num_nodes;
     const int time_limit = inst->params.time_limit > 0 ? inst->params.time_limit : DEFAULT_TIME_LIM;
@@ -368,24 +409,42 @@ int tsp_host_vns(instance *inst, long long max_rounds) {
     gettimeofday(&t0, 0);
     int status = HEU_2opt_greedy_iter(inst);                 /* :116 */
     double best_obj = inst->solution.obj_best;
-    edge *best = malloc(sizeof(edge) * (size_t)n);
-    memcpy(best, inst->solution.edges, sizeof(edge) * (size_t)n);
-    for (long long round = 0; max_rounds < 0 || round < max_rounds; round++) {
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_inst *d = dev_inst_locked(inst);
+    tsp_dev_tours *t = NULL;
+    int rc = tsp_dev_tours_create(d, 1, &t);
+    if (!rc) rc = tsp_dev_tours_upload(t, &inst->solution.edges[0].j, 2, 2 * (int64_t)n, &best_obj);
+    if (!rc) rc = tsp_dev_tours_snapshot(t);                 /* the incumbent, :119-122 */
+    pthread_mutex_unlock(&g_lock);
+    if (rc) dev_fail("tsp_host_vns: resident tour", rc);
+    long long rounds = 0;
+    for (long long round = 0; max_rounds < 0 || round < max_rounds; round++, rounds++) {
         gettimeofday(&t1, 0);
         if (get_elapsed_time(t0, t1) > time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
-        kick(inst);
-        status = alg_2opt(inst);
-        if (inst->solution.obj_best < best_obj) {
-            best_obj = inst->solution.obj_best;
-            memcpy(best, inst->solution.edges, sizeof(edge) * (size_t)n);
-            if (inst->params.verbose >= 3) LOG_I("Updated incumbent: %0.0f", best_obj);
+        int p1, p2, p3;
+        kick_positions(n, &p1, &p2, &p3);                    /* :138 */
+        double obj = 0.0;
+        pthread_mutex_lock(&g_lock);
+        rc = tsp_dev_tours_vns_kick(t, p1, p2, p3, NULL);
+        if (!rc) { rc = tsp_dev_tours_two_opt(t, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, limit_of(inst), &obj); if (rc > 0) { status = rc; rc = 0; } else status = 0; }   /* :143 */
+        if (!rc) {
+            if (obj < best_obj) { best_obj = obj; rc = tsp_dev_tours_snapshot(t); }     /* :148-155 */
+            else rc = tsp_dev_tours_restore(t);                                            /* :157-158 */
         }
-        inst->solution.obj_best = best_obj;                  /* :157-158: always restart from the incumbent */
-        memcpy(inst->solution.edges, best, sizeof(edge) * (size_t)n);
+        pthread_mutex_unlock(&g_lock);
+        if (rc) dev_fail("tsp_host_vns: round", rc);
+        if (inst->params.verbose >= 3 && obj == best_obj) LOG_I("Updated incumbent: %0.0f", best_obj);
     }
+    pthread_mutex_lock(&g_lock);
+    rc = tsp_dev_tours_restore(t);
+    pthread_mutex_unlock(&g_lock);
+    if (rc) dev_fail("tsp_dev_tours_restore", rc);
+    download_into(inst, t);
     inst->solution.obj_best = best_obj;
-    memcpy(inst->solution.edges, best, sizeof(edge) * (size_t)n);
-    free(best);
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_tours_destroy(t);
+    pthread_mutex_unlock(&g_lock);
+    (void)rounds;
     return status;
 }
 
@@ -393,70 +452,51 @@ int HEU_VNS(instance *inst) { return tsp_host_vns(inst, -1); }
 
 /* ---- tabu search (src/tabusearch.c:188-320) ---------------------------------------------------------------- */
 
-/* The stamps stay on the device for the whole search (the reference CALLOCs num_columns ints, :195).
- * check_tenure's lazy clearing (:83-92) in the kick's `&&` chain (:282-285) is replayed on the host
- * from one 4-stamp read; the clears it implies are written back. */
-static int kick_edges_free(tsp_dev_tabu *tb, const int idx[4], int iter, int tenure) {
-    int val[4];
-    int rc = tsp_dev_tabu_get(tb, idx, val, 4);
-    if (rc) dev_fail("tsp_dev_tabu_get", rc);
-    int clear_idx[4], zeros[4] = {0, 0, 0, 0}, nclear = 0, is_free = 1;
-    for (int k = 0; k < 4; k++) {
-        if (iter < 0 || tenure < 0 || val[k] == 0) continue;
-        if (iter - val[k] > tenure) { clear_idx[nclear++] = idx[k]; continue; }
-        is_free = 0;                                         /* in the tabu list: the chain stops here */
-        break;
-    }
-    if (nclear) { rc = tsp_dev_tabu_set(tb, clear_idx, zeros, nclear); if (rc) dev_fail("tsp_dev_tabu_set", rc); }
-    return is_free;
-}
-
+/* The tour and the stamps stay on the device for the whole search (the reference CALLOCs num_columns ints, :195): an
+ * iteration is alg_2opt_tabu on the resident tour, an 8-byte read of its cost, a device-to-device copy when the incumbent
+ * improves (:241-249), and the kick (:262-309) -- one tiny launch per trial that tests (a,a1) (b,b1) (a,b) (a1,b1) against
+ * the tabu list with check_tenure's lazy clears, carries the 2-exchange out and stamps the removed edges; the host only
+ * draws a and b and steps the tenure policy. */
 int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
     const int n = inst->num_nodes;
-    edge *e = inst->solution.edges;
     struct timeval t0, t1;
     gettimeofday(&t0, 0);
     int status = HEU_2opt_greedy_iter(inst);                 /* :200 */
     if (status) LOG_E("An error occurred in HEU_2opt_greedy_iter");
+    double obj0 = inst->solution.obj_best;
     pthread_mutex_lock(&g_lock);
     tsp_dev_inst *d = dev_inst_locked(inst);
     tsp_dev_tabu *tb = NULL;
+    tsp_dev_tours *t = NULL;
     int rc = tsp_dev_tabu_create(d, &tb);
+    if (!rc) rc = tsp_dev_tours_create(d, 1, &t);
+    if (!rc) rc = tsp_dev_tours_upload(t, &inst->solution.edges[0].j, 2, 2 * (int64_t)n, &obj0);
     pthread_mutex_unlock(&g_lock);
-    if (rc) dev_fail("tsp_dev_tabu_create", rc);
-    int *prev = calloc((size_t)n, sizeof(int));
+    if (rc) dev_fail("tsp_host_tabu: resident state", rc);
     double best_obj = DBL_MAX;
-    edge *best = calloc((size_t)n, sizeof(edge));
+    int have_best = 0;
     int lo = (int)ceil(n * 0.02), hi = (int)round(n * 0.1);  /* :213-214, MIN/MAX_TENURE_RATE :12-13 */
-    if (lo == hi) hi += 2; else if (hi < lo) { int t = lo; lo = hi; hi = t; }
+    if (lo == hi) hi += 2; else if (hi < lo) { int tt = lo; lo = hi; hi = tt; }
     int tenure = lo, rising = 0;
     for (int iter = 1; max_iterations < 0 || iter <= max_iterations; iter++) {
         gettimeofday(&t1, 0);
         if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
-        tsp_two_opt_stats st;
-        memset(&st, 0, sizeof st);
-        double obj = inst->solution.obj_best;
+        double obj = 0.0;
         pthread_mutex_lock(&g_lock);
-        rc = tsp_dev_two_opt_tabu(d, tb, iter, tenure, &e[0].j, 2, &obj, prev, limit_of(inst), &st);   /* :238 */
+        rc = tsp_dev_tours_two_opt_tabu(t, tb, iter, tenure, limit_of(inst), &obj);   /* :238 */
+        if (rc >= 0 && obj < best_obj) { best_obj = obj; have_best = 1; int rc2 = tsp_dev_tours_snapshot(t); if (rc2) rc = rc2; }   /* :241-249 */
         pthread_mutex_unlock(&g_lock);
-        if (rc < 0) dev_fail("tsp_dev_two_opt_tabu", rc);
-        inst->solution.obj_best = obj;
-        keep_stats(&st);
-        if (obj < best_obj) { best_obj = obj; memcpy(best, e, sizeof(edge) * (size_t)n); }
+        if (rc < 0) dev_fail("tsp_dev_tours_two_opt_tabu", rc);
         if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
-        int a, b, a1, b1;
-        for (;;) {                                           /* :262-287 */
-            a = rand_choice(0, n); b = rand_choice(0, n);
-            a1 = e[a].j; b1 = e[b].j;
-            if (a == b || a1 == b || b1 == a) continue;
-            const int idx[4] = {x_udir_pos(a, a1, n), x_udir_pos(b, b1, n), x_udir_pos(a, b, n), x_udir_pos(a1, b1, n)};
+        for (;;) {                                           /* :262-287: draws until a pair of free, disjoint edges comes up */
+            const int a = rand_choice(0, n), b = rand_choice(0, n);
+            int accepted = 0;
             pthread_mutex_lock(&g_lock);
-            const int ok = kick_edges_free(tb, idx, iter, tenure);
+            rc = tsp_dev_tours_tabu_kick(t, tb, a, b, iter, tenure, &accepted);   /* + :288-290 move, :306-309 stamps */
             pthread_mutex_unlock(&g_lock);
-            if (ok) break;
+            if (rc) dev_fail("tsp_dev_tours_tabu_kick", rc);
+            if (accepted) break;
         }
-        e[a].j = b; e[a1].j = b1;
-        reverse_path(inst, b, a1, prev);
         if (policy == 0) {                                   /* step_policy :33-37 */
             if (iter % 100 == 0) tenure = (tenure == lo) ? hi : lo;
         } else if (policy == 1) {                            /* linear_policy :47-59 */
@@ -467,18 +507,17 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         } else {                                             /* random_policy :69-72 */
             if (iter == 1 || iter % 100 == 0) tenure = rand_choice(lo, hi + 1);
         }
-        const int sidx[2] = {x_udir_pos(a, a1, n), x_udir_pos(b, b1, n)}, sval[2] = {iter, iter};
-        pthread_mutex_lock(&g_lock);
-        rc = tsp_dev_tabu_set(tb, sidx, sval, 2);            /* :306-309 */
-        pthread_mutex_unlock(&g_lock);
-        if (rc) dev_fail("tsp_dev_tabu_set", rc);
     }
-    inst->solution.obj_best = best_obj;
-    memcpy(e, best, sizeof(edge) * (size_t)n);
     pthread_mutex_lock(&g_lock);
+    rc = have_best ? tsp_dev_tours_restore(t) : 0;
+    pthread_mutex_unlock(&g_lock);
+    if (rc) dev_fail("tsp_dev_tours_restore", rc);
+    download_into(inst, t);
+    if (have_best) inst->solution.obj_best = best_obj;
+    pthread_mutex_lock(&g_lock);
+    tsp_dev_tours_destroy(t);
     tsp_dev_tabu_destroy(tb);
     pthread_mutex_unlock(&g_lock);
-    free(prev); free(best);
     return status;
 }
 
