@@ -76,6 +76,7 @@ def lib():
         L.orc_tabu.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp, C.c_longlong,
                                C.POINTER(C.c_longlong)]
         L.orc_genetic.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_longlong, ip, dp]
+        L.orc_genetic_ex.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_double, ip, dp]
         L.orc_srandom.argtypes = [C.c_uint]
         L.orc_urand.restype = C.c_double
         L.orc_parse_tsplib.argtypes = [C.c_char_p, dp, C.c_int, ip]
@@ -243,12 +244,13 @@ def tabu(xy, wtype, succ, obj, iterations, policy=0, integer_cost=1):
     return succ, o.value, mv.value
 
 
-def genetic(xy, wtype, generations, integer_cost=1):
-    """-> (incumbent succ, incumbent cost) after `generations` generations (draws from libc random())"""
+def genetic(xy, wtype, generations, integer_cost=1, two_opt_prob=0.0):
+    """-> (incumbent succ, incumbent cost) after `generations` generations (draws from libc random());
+    two_opt_prob = probability of mutation method 3 (0.00 in the reference, genetic.c:18)"""
     xy = _xy(xy)
     succ = np.zeros(len(xy), dtype=np.int32)
     o = C.c_double(0)
-    lib().orc_genetic(_d(xy), len(xy), wtype, integer_cost, generations, _i(succ), C.byref(o))
+    lib().orc_genetic_ex(_d(xy), len(xy), wtype, integer_cost, generations, two_opt_prob, _i(succ), C.byref(o))
     return succ, o.value
 
 

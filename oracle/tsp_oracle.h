@@ -120,6 +120,9 @@ int orc_tabu(const double *xy, int n, int wtype, int integer_cost, int policy, i
  * rank-roulette survivors incl. the reference's chromosome aliasing) with a generation cap; the incumbent
  * tour / cost are written whenever a generation's best improves on them (:518-526). */
 int orc_genetic(const double *xy, int n, int wtype, int integer_cost, long long generations, int *succ, double *obj);
+/* the same with the probability of mutation method 3 (2-opt, genetic.c:426-443) as an argument; 0.00 in the reference */
+int orc_genetic_ex(const double *xy, int n, int wtype, int integer_cost, long long generations, double two_opt_prob,
+                   int *succ, double *obj);
 
 /* libc RNG access so that tests can reproduce the reference's stream (src/solver.c:264-266) */
 void orc_srandom(unsigned seed);

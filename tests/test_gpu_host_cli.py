@@ -66,6 +66,7 @@ def host():
     L.tsp_host_vns.argtypes = [C.POINTER(Instance), C.c_longlong]
     L.tsp_host_tabu.argtypes = [C.POINTER(Instance), C.c_int, C.c_longlong]
     L.tsp_host_genetic.argtypes = [C.POINTER(Instance), C.c_longlong]
+    L.tsp_host_genetic_ex.argtypes = [C.POINTER(Instance), C.c_longlong, C.c_double]
     yield L
     L.tsp_host_shutdown()
 
@@ -271,6 +272,21 @@ def test_genetic_generations_match_oracle(host, name, gens):
     # NOT asserted: obj == cost(tour).  The reference never refreshes an offspring's fitness after mutating it
     # (genetic.c:375-446) and copies aliased chromosomes in choose_survivors (:266-331), so its reported
     # incumbent value can belong to a different chromosome; both restatements keep that behaviour.
+
+
+@pytest.mark.parametrize("name,gens,prob", [("berlin52", 25, 0.5), ("pr299", 6, 0.3)])
+def test_genetic_with_two_opt_mutation_matches_oracle(host, name, gens, prob):
+    """Mutation method 3 (genetic.c:426-443: alg_2opt on the offspring) is compiled out of the reference by
+    TWO_OPT_MUTATION_PROB 0.00; with the probability raised both sides execute it -- the host mirror refines all such
+    offspring of a generation in ONE batched device call, the oracle (an independent, function-by-function restatement of
+    genetic.c on the reference's own data structures) one by one on the CPU -- and the incumbent must stay equal."""
+    h = HostInstance(name)
+    h.c.params.time_limit = 600
+    O.srandom(123)
+    rc = host.tsp_host_genetic_ex(C.byref(h.c), gens, prob)
+    O.srandom(123)
+    es, eo = O.genetic(h.xy, h.wt, gens, two_opt_prob=prob)
+    assert rc == 0 and h.obj == eo and (h.succ == es).all() and O.is_tour(h.succ)
 
 
 def test_cli_vns_and_tabu_respect_the_time_limit():

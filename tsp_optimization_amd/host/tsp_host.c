@@ -590,11 +590,11 @@ static void ga_crossover(int n, const int *p1, const int *p2, int *child, char *
 }
 
 /* :375-446 without its 2-opt branch (handled by the caller); returns 1 if that branch was drawn */
-static int ga_mutate_one(int n, int *genes) {
+static int ga_mutate_one(int n, int *genes, double two_opt_prob) {
     const double u = URAND();
     if (!(u < GA_MUTATION_RATE)) return 0;
     const double method = URAND();
-    if (!(method > GA_TWO_OPT_MUT)) return 1;
+    if (!(method > two_opt_prob)) return 1;
     int lo = rand_choice(0, n - 1), hi = rand_choice(0, n - 1);
     if (lo > hi) { const int t = lo; lo = hi; hi = t; }
     if (lo == hi) { if (lo > 0) lo -= 1; else hi += 1; }
@@ -624,7 +624,7 @@ static void ga_choose_survivors(int n, ga_member *pop, int pop_size, const ga_me
 }
 
 /* :448-565 with a cap on the number of generations in addition to the time limit */
-int tsp_host_genetic(instance *inst, long long max_generations) {
+int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_opt_prob) {
     const int n = inst->num_nodes;
     struct timeval t0, t1;
     gettimeofday(&t0, 0);
@@ -632,6 +632,9 @@ int tsp_host_genetic(instance *inst, long long max_generations) {
     int *pop_slab = calloc((size_t)pop_size * n, sizeof(int)), *kid_slab = calloc((size_t)kid_count * n, sizeof(int));
     ga_member *pop = calloc((size_t)pop_size, sizeof(ga_member)), *kids = calloc((size_t)kid_count, sizeof(ga_member));
     double *fit = malloc(sizeof(double) * (size_t)pop_size);
+    int *two_opt_kids = malloc(sizeof(int) * (size_t)kid_count);
+    int *two_opt_succ = malloc(sizeof(int) * (size_t)kid_count * n);
+    double *two_opt_obj = malloc(sizeof(double) * (size_t)kid_count);
     for (int k = 0; k < pop_size; k++) {
         pop[k].genes = pop_slab + (size_t)k * n;
         const double u = URAND();                            /* :463 */
@@ -671,22 +674,38 @@ int tsp_host_genetic(instance *inst, long long max_generations) {
             ga_crossover(n, pop[parents[k]].genes, pop[parents[(k + 1) % parent_count]].genes, kids[k].genes, seen);
         fitness_batch(inst, kid_slab, kid_count, fit);       /* :251, all offspring in one launch (no draws in between) */
         for (int k = 0; k < kid_count; k++) kids[k].fit = fit[k];
+        /* mutation :375-446.  Method 3 (alg_2opt on a private copy, :426-443) draws nothing and touches only its own
+         * offspring, so the offspring that drew it are refined together after the loop: one batched device call per
+         * generation instead of one copy_instance + alg_2opt per offspring. */
+        int n2 = 0;
         for (int k = 0; k < kid_count; k++)
-            if (ga_mutate_one(n, kids[k].genes)) {           /* mutation method 3, :426-443: alg_2opt on a private copy */
-                instance tmp;
-                copy_instance(&tmp, inst);
-                for (int q = 0; q < n; q++) { tmp.solution.edges[kids[k].genes[q]].i = kids[k].genes[q]; tmp.solution.edges[kids[k].genes[q]].j = kids[k].genes[q + 1 == n ? 0 : q + 1]; }
-                tmp.params.time_limit = 2;
-                alg_2opt(&tmp);
-                for (int q = 0, v = 0; q < n; q++) { kids[k].genes[q] = tmp.solution.edges[v].i; v = tmp.solution.edges[v].j; }
-                free_instance(&tmp);
+            if (ga_mutate_one(n, kids[k].genes, two_opt_prob)) two_opt_kids[n2++] = k;
+        if (n2 > 0) {
+            for (int m = 0; m < n2; m++) {
+                const int *g = kids[two_opt_kids[m]].genes;
+                int *sp = two_opt_succ + (size_t)m * n;
+                for (int q = 0; q < n; q++) sp[g[q]] = g[q + 1 == n ? 0 : q + 1];     /* from_chromosome_to_edges :33-42 */
+                two_opt_obj[m] = inst->solution.obj_best;                              /* copy_instance keeps obj_best; alg_2opt adds deltas to it */
             }
+            pthread_mutex_lock(&g_lock);
+            int rc = tsp_dev_two_opt(dev_inst_locked(inst), TSP_2OPT_FIRST, TSP_ENGINE_AUTO, n2, two_opt_succ, 1, n, two_opt_obj,
+                                     2.0 /* :432 */, NULL);
+            pthread_mutex_unlock(&g_lock);
+            if (rc < 0) dev_fail("tsp_dev_two_opt (GA mutation)", rc);
+            for (int m = 0; m < n2; m++) {                                             /* :436-441: the walk from node 0 */
+                int *g = kids[two_opt_kids[m]].genes;
+                const int *sp = two_opt_succ + (size_t)m * n;
+                for (int q = 0, v = 0; q < n; q++) { g[q] = v; v = sp[v]; }
+            }
+        }
         ga_choose_survivors(n, pop, pop_size, kids, kid_count);
     }
     free(pop_slab); free(kid_slab); free(pop); free(kids); free(fit); free(parents); free(seen);
+    free(two_opt_kids); free(two_opt_succ); free(two_opt_obj);
     return status;
 }
 
+int tsp_host_genetic(instance *inst, long long max_generations) { return tsp_host_genetic_ex(inst, max_generations, GA_TWO_OPT_MUT); }
 int HEU_Genetic(instance *inst) { return tsp_host_genetic(inst, -1); }
 
 /* genetic.c:51-60 for `count` chromosomes of n nodes each */

@@ -146,6 +146,9 @@ int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, d
 int tsp_host_vns(instance *inst, long long max_rounds);
 int tsp_host_tabu(instance *inst, int policy, long long max_iterations);
 int tsp_host_genetic(instance *inst, long long max_generations);
+/* the same with the probability of mutation method 3 (alg_2opt on the offspring, genetic.c:426-443) as an argument:
+ * TWO_OPT_MUTATION_PROB is 0.00 in the reference (genetic.c:18); tests raise it so that the branch is executed */
+int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_opt_prob);
 /* Counters of the last alg_2opt / alg_2opt_tabu call of this thread. */
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms);
 /* Releases the cached device context / instances (optional; also done at exit). */
