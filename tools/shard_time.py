@@ -1,0 +1,31 @@
+"""What one rank of an N-GPU job would spend on its shard of BASELINE configs[3] / [4] (run on one GPU through gpurun):
+rank 0's shard for world = 1, 2, 4, 8, default engine policy, and with the CLUSTER engine switched off (TSP_ENGINE=2)."""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import numpy as np
+from tsp_optimization_amd import engine as E, multistart as MS, tsplib
+
+ctx = E.Context(0)
+xy, wt = tsplib.parse(os.path.join(R, "tests", "golden", "instances", "att532.tsp"))
+inst4 = E.Instance(ctx, xy, wt, 1)
+rng = MS.LibcRandom(123)
+starts, stream = MS.grasp_stream(rng.urand, len(xy), 256)
+xy5 = np.random.default_rng(5000).integers(0, 1_000_000, size=(5000, 2)).astype(np.float64)
+inst5 = E.Instance(ctx, xy5, E.EUC_2D, 1)
+rng = MS.LibcRandom(123)
+perms = np.stack([rng.random_perm(5000) for _ in range(128)])
+for force in (None, "2"):
+    if force: os.environ["TSP_ENGINE"] = force
+    else: os.environ.pop("TSP_ENGINE", None)
+    for world in (1, 2, 4, 8):
+        r4 = MS.config4_refiner(E, inst4, starts, stream)
+        r5 = MS.config5_refiner(E, inst5, perms)
+        ids4, ids5 = MS.shard_starts(256, 0, world), MS.shard_starts(128, 0, world)
+        r4(ids4[:2])
+        t0 = time.perf_counter(); r4(ids4); t4 = time.perf_counter() - t0
+        d4 = r4.stats[0]["device_ms"]
+        t0 = time.perf_counter(); r5(ids5); t5 = time.perf_counter() - t0
+        d5 = r5.stats[0]["device_ms"]
+        print("engine %-7s world %d: config4 %3d starts %.2f ms (2-opt device %.2f ms)   config5 %3d individuals %.1f ms (2-opt device %.1f ms)"
+              % ("auto" if not force else "LDS", world, len(ids4), 1e3 * t4, d4, len(ids5), 1e3 * t5, d5), flush=True)

@@ -411,8 +411,11 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         const bool cl_mode_ok = mode == TSP_2OPT_FIRST || tsp_cluster_sorted(t, mode);
         bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
         // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
-        if (lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299) lds = true;
-        bool cluster = C >= 4 && cl_mode_ok;
+        const bool small_single = lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299;
+        if (small_single) lds = true;
+        // first improvement: many workgroups only pay where the scan, not the per-move latency, dominates or CUs would idle;
+        // eight or more tours go one workgroup per tour (LDS) unless that would leave most of the chip idle
+        bool cluster = cl_mode_ok && !small_single && (mode == TSP_2OPT_BEST ? C >= 4 : (C >= 4 && (B < 8 || C >= 8)));
         if (force && *force == '1') { lds = false; cluster = false; }
         if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
         if (force && *force == '3' && C >= 1) cluster = true;

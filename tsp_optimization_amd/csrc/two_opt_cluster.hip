@@ -63,7 +63,7 @@ struct ClusterArgs {
     const int *pairtab;     // sorted: C x ntests group pairs (r << 16 | c, -1 = none), nearest first, dealt in turn
     unsigned long long *slots;   // B x 2 x C x kClSlotGranules
     int *err;
-    int n, nid, ng, ntests, C, max_iters, rmin, rmax, count_evals;
+    int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, count_evals;
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
     double org_x, org_y;    // float replicas hold coordinates relative to this corner (exact: bounded integers)
@@ -740,7 +740,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (found) {
                 obj += bd;                              // heuristics.c:486
                 moves += 1; reversed += Lr - 1;
-                ci = wi; cj = wj; chunk = a.rmin;
+                // the next chunk: twice the rows this hit was away from the cursor -- dense phases (a random tour: a hit
+                // in almost every row) scan a row or two per step, sparse ones keep the chunk that found something
+                chunk = max(a.rmin, min(a.rcap, 2 * (wi - ci + 1)));
+                ci = wi; cj = wj;
             } else {
                 chunk = min(chunk * 2, a.rmax);
                 if (row_hi >= n - 1) {                  // sweep complete
@@ -960,11 +963,14 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.stage_pairs = p.stage_pairs;
     a.org_x = inst->org_x; a.org_y = inst->org_y;
     a.margin = inst->filter_margin; a.prune = inst->prune_margin; a.sum_margin = inst->sum_margin;
-    // FIRST chunk geometry: a step costs a few microseconds whatever it scans, so the smallest chunk grows with the
-    // cluster (about 4000 pairs per workgroup), the largest keeps every workgroup busy for a few tiles
-    const long long per_step = 4000ll * C;
-    const int auto_rmin = (int)std::max<long long>(1, std::min<long long>(64, (per_step + n / 2) / n));
-    a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", auto_rmin)));
+    // FIRST chunk geometry: the chunk adapts to the distance between hits (see the kernel's control block); the largest
+    // keeps every workgroup busy for a few tiles
+    {   // rows that cost (almost) nothing more than one: every workgroup at most one tile of at most two rows (measured:
+        // rand10000 on 256 workgroups is best at 24-36 rows, 16 random tours of rand5000 on 16 workgroups each at 1-2)
+        const int nb = (n + kClThreads - 1) / kClThreads;
+        a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", std::max(1, 2 * (C / nb)))));
+        a.rcap = std::max(a.rmin, env_int("TSP_CLUSTER_HIT_CAP", 4) * a.rmin);   // largest chunk right after a hit
+    }
     a.rmax = std::max(a.rmin, std::min(2048, env_int("TSP_CLUSTER_MAX_ROWS", C == 1 ? kClRows : std::max(kClRows, 8 * C))));
     // steps per launch: a time limit is honoured between launches (the reference checks it per sweep / per pair), so a
     // limited run is cut into launches of a millisecond or two (a relaunch reloads the replicas: ~0.1 ms)
