@@ -219,23 +219,39 @@ int grasp(instance *inst, int starting_node) {
 int HEU_greedy(instance *inst) { return greedy(inst, 0); } /* :160 */
 int HEU_Grasp(instance *inst) { return grasp(inst, 0); }   /* :505 */
 
-/* :168-205 -- all n starting nodes in one batched device call; the first strictly better start wins */
+/* :168-205 -- all n starting nodes, in batched device calls of at most GREEDY_ITER_BATCH starts (O(n) host memory per start
+ * in flight, like the reference's O(n) state, instead of an n x n array); the first strictly better start wins (:193) and the
+ * time limit is honoured between batches (:183 checks it per start) */
+#define GREEDY_ITER_BATCH 1024
 int HEU_Greedy_iter(instance *inst) {
     const int n = inst->num_nodes;
-    int *starts = malloc(sizeof(int) * (size_t)n);
-    int *succ = malloc(sizeof(int) * (size_t)n * n);
-    double *obj = malloc(sizeof(double) * (size_t)n);
-    for (int k = 0; k < n; k++) starts[k] = k;
-    pthread_mutex_lock(&g_lock);
-    int rc = tsp_dev_construct(dev_inst_locked(inst), TSP_CONSTRUCT_GREEDY, n, starts, NULL, succ, 1, n, obj, NULL);
-    pthread_mutex_unlock(&g_lock);
-    if (rc < 0) dev_fail("tsp_dev_construct", rc);
-    int best = 0;
-    for (int k = 1; k < n; k++) if (obj[k] < obj[best]) best = k;
-    for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = succ[(size_t)best * n + v]; }
-    inst->solution.obj_best = obj[best];
+    const int B = n < GREEDY_ITER_BATCH ? n : GREEDY_ITER_BATCH;
+    int *starts = malloc(sizeof(int) * (size_t)B);
+    int *succ = malloc(sizeof(int) * (size_t)B * n);
+    double *obj = malloc(sizeof(double) * (size_t)B);
+    if (!starts || !succ || !obj) LOG_E("HEU_Greedy_iter: out of memory");
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    double best = DBL_MAX;
+    int status = 0;
+    for (int k0 = 0; k0 < n; k0 += B) {
+        const int m = n - k0 < B ? n - k0 : B;
+        for (int k = 0; k < m; k++) starts[k] = k0 + k;
+        pthread_mutex_lock(&g_lock);
+        int rc = tsp_dev_construct(dev_inst_locked(inst), TSP_CONSTRUCT_GREEDY, m, starts, NULL, succ, 1, n, obj, NULL);
+        pthread_mutex_unlock(&g_lock);
+        if (rc < 0) dev_fail("tsp_dev_construct", rc);
+        for (int k = 0; k < m; k++)
+            if (obj[k] < best) {
+                best = obj[k];
+                for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = succ[(size_t)k * n + v]; }
+            }
+        gettimeofday(&t1, 0);
+        if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit && k0 + B < n) { status = TIME_LIMIT_EXCEEDED; break; }
+    }
+    inst->solution.obj_best = best;
     free(starts); free(succ); free(obj);
-    return 0;
+    return status;
 }
 
 /* :510-544 -- wall-clock bounded random restarts.  The RNG stream is consumed in the reference's
