@@ -117,7 +117,25 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     // there (x + y) - x - y can round to a tiny negative.
     constexpr bool EXACT_SUMS = INT || WT == WT_CEIL_2D || WT == WT_CEIL_2D_ICOORD;
     const bool plain_tile = MODE == TSP_2OPT_BEST && !TABU && FILTER && EXACT_SUMS && c0 >= r1 && c0 + TJ <= n;
-    if (plain_tile) {
+    // bounds switched off (TSP_NO_FILTER=1, margins 1e300): every delta expression is executed, and nothing else -- no
+    // bound arithmetic that could never exclude a pair.  This is the exhaustive sweep bench.py's roofline.exhaustive times.
+    const bool exhaustive = MODE == TSP_2OPT_BEST && !TABU && FILTER && a.margin > 1e299;
+    if (exhaustive) {
+        for (int ib = r0; ib < r1; ib += 2) {   // two rows in flight: the root is a long dependent chain
+            const int i0 = ib, i1 = min(ib + 1, r1 - 1);
+            const NodeRec ra = s_rows[i0 - r0], rb = s_rows[i1 - r0];
+            const bool two = ib + 1 < r1;
+#pragma unroll
+            for (int k = 0; k < RJ; ++k) {
+                const double da = pair_delta<WT, INT>(ra, rj[k]), db = pair_delta<WT, INT>(rb, rj[k]);
+                const int j = jc[k];
+                const bool oka = plain_tile || (j > i0 && j != ra.succ && rj[k].succ != i0);   // heuristics.c:471 / tabusearch.c:134
+                const bool okb = two && (plain_tile || (j > i1 && j != rb.succ && rj[k].succ != i1));
+                if (oka && da < bd) { bd = da; bi = i0; bj = j; }
+                if (okb && db < bd) { bd = db; bi = i1; bj = j; }
+            }
+        }
+    } else if (plain_tile) {
         for (int i = r0; i < r1; ++i) {
             const NodeRec ri = s_rows[i - r0];
             const double row_bias = ri.ds + a.margin;
