@@ -1,6 +1,7 @@
-"""Randomised parity sweep (one-off, run through gpurun): random sizes around the tile / group / batch boundaries,
-random metrics and cost modes, random tours; both rules, forced sorted sweep, both construction kernels -- all
-against the oracle.  Prints the first mismatch and exits non-zero."""
+"""Randomised parity sweep (run through gpurun): random sizes around the tile / group / batch boundaries, random metrics
+and cost modes, random tours; both rules, forced sorted sweep / sorted scan, both construction kernels, GRID engine and
+CLUSTER engine with a random cluster size -- all against the oracle.  Prints the first mismatch and exits non-zero.
+SEED=<n> CASES=<n> select the run."""
 import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -44,6 +45,14 @@ for c in range(cases):
     rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
     _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
     ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+    # the same two descents on the CLUSTER engine with a random number of workgroups per tour
+    os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 8, 17, 64, 200, 256])))
+    if n <= 300:
+        rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)
+        ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+    rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
+    ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+    del os.environ["TSP_CLUSTER_BLOCKS"]
     if c % 3 == 0 and n >= 8:
         # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
         t3 = np.stack([random_tour(n, rng) for _ in range(3)])
