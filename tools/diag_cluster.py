@@ -34,6 +34,10 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         print('  %-22s mean %6.2f  min %6.2f  max %6.2f us/step' % (names[k], col.mean(), col.min(), col.max()))
     print('  %-22s mean %6.2f us/step' % ('sum', (a[used, :6].sum(1) / 100.0 / steps).mean()))
     L.tsp_dev_debug_cluster_counts(cnt)
+    if mode == E.FIRST:
+        nb = int(used.sum())
+        print('  inside the scan (thread 0, mean over workgroups): before tile %.2f  derive+barriers %.2f  row loop %.2f us/step; tiles per workgroup and step %.2f'
+              % (cnt[0] / 100.0 / steps / nb, cnt[1] / 100.0 / steps / nb, cnt[2] / 100.0 / steps / nb, cnt[3] / steps / nb))
     if mode == E.BEST:
         nb = int(used.sum())
         print('  inside the scan (thread 0, mean over workgroups): stage+culling %.2f  (-) %.2f  rows+queues %.2f us/step (the rest: final barrier); live rows per workgroup and step %.1f'

@@ -63,7 +63,7 @@ struct ClusterArgs {
     const int *pairtab;     // sorted: C x ntests group pairs (r << 16 | c, -1 = none), nearest first, dealt in turn
     unsigned long long *slots;   // B x 2 x C x kClSlotGranules
     int *err;
-    int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, count_evals;
+    int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
     double org_x, org_y;    // float replicas hold coordinates relative to this corner (exact: bounded integers)
@@ -169,6 +169,15 @@ __device__ __forceinline__ double cl_dist(const CT *coord, int u, int v) {
     return dist_xy<WT, INT>((double)a.x, (double)a.y, (double)b.x, (double)b.y);
 }
 
+// a / b for 0 <= a < 2^22, 0 < b < 2^22 without the integer-division expansion (~40 instructions each; a first-improvement
+// step needs three of them before its first tile): float quotient, one correction either way
+__device__ __forceinline__ int cl_div(int a, int b) {
+    int q = (int)((float)a / (float)b);
+    if (q * b > a) --q;
+    if ((q + 1) * b <= a) ++q;
+    return q;
+}
+
 // max over the 64 lanes of a non-negative double (orders like its bits)
 __device__ __forceinline__ double cl_wave_max_nonneg(double v) {
     const u64 mb = ~wave_min_u64(~(u64)__double_as_longlong(v));
@@ -216,19 +225,25 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
     }
     constexpr int Q = 4;   // C <= 256: at most four candidates per lane
     u64 g[Q][NG];
+    bool have[Q];          // candidate q of this lane is complete: later passes leave it alone (fewer requests on the hot lines)
+#pragma unroll
+    for (int q = 0; q < Q; ++q) have[q] = q * 64 + lane >= C;
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const int k = q * 64 + lane;
             if (q * 64 < C) {   // wave-uniform
-                if (k < C) {
+                if (!have[q]) {
+                    const int k = q * 64 + lane;
 #pragma unroll
                     for (int w = 0; w < NG; ++w)
                         g[q][w] = __hip_atomic_load(par + (size_t)w * C + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool all = true;
 #pragma unroll
-                    for (int w = 0; w < NG; ++w) ok = ok && (g[q][w] >> 32) == (u64)ep;
+                    for (int w = 0; w < NG; ++w) all = all && (g[q][w] >> 32) == (u64)ep;
+                    have[q] = all;
+                    ok = ok && all;
                 }
             }
         }
@@ -556,13 +571,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             // 236 of 256 workgroups idle and make the 20 busy ones eight times slower than they need be)
             const int nb = (n + kClThreads - 1) / kClThreads;
             const int nrows = row_hi - row_lo;
-            const int rbs = C / nb;   // row blocks that give every workgroup at most one tile
-            const int rpt = rbs > 0 ? max(1, min(kClRows, (nrows + rbs - 1) / rbs)) : kClRows;
-            const int nrb = (nrows + rpt - 1) / rpt;
+            const int rbs = a.rbs;    // C / nb: row blocks that give every workgroup at most one tile
+            const int rpt = rbs > 0 ? max(1, min(kClRows, cl_div(nrows + rbs - 1, rbs))) : kClRows;
+            const int nrb = cl_div(nrows + rpt - 1, rpt);
             int hit_rb = nrb;   // FIRST: first row block in which this workgroup has found an improving pair
             bool any_hit = false;
             for (int t = c; t < nrb * nb; t += C) {
-                const int rbi = t / nb, b = t - rbi * nb;
+                const int rbi = cl_div(t, nb), b = t - rbi * nb;
                 if (!BEST && rbi > hit_rb) break;   // later rows only hold later pairs
                 const int rb = row_lo + rbi * rpt;
                 const int nr = min(rpt, row_hi - rb);
@@ -570,12 +585,17 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 // no column of this batch above the first row (or, in the cursor's row alone, above the cursor)
                 const int jmin = (!BEST && nr == 1 && rb == ci) ? max(rb, cj) : rb;
                 if (b * kClThreads + kClThreads - 1 <= jmin) continue;
+                CL_T(8);
                 __syncthreads();
                 if (tid < nr) s_rows[tid] = cl_node<WT, INT, CT>(coord, order, pos, n, rb + tid);
                 NodeRec rj;
                 const bool act = j < n && j > rb;
                 if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
                 __syncthreads();
+                CL_T(9);
+#ifdef TSP_STAMPS
+                if (tid == 0) prof[11] += 1;
+#endif
                 w_lane += (long long)nr * __popcll(__ballot(act));
                 {
                     for (int r = 0; r < nr; ++r) {
@@ -605,6 +625,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         }
                     }
                 }
+                CL_T(10);
                 if constexpr (!BEST) {
                     if (!any_hit && __syncthreads_or(key != kNoKey)) { any_hit = true; hit_rb = rbi; }
                 }
@@ -970,6 +991,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         const int nb = (n + kClThreads - 1) / kClThreads;
         a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", std::max(1, 2 * (C / nb)))));
         a.rcap = std::max(a.rmin, env_int("TSP_CLUSTER_HIT_CAP", 4) * a.rmin);   // largest chunk right after a hit
+        a.rbs = C / nb;
     }
     a.rmax = std::max(a.rmin, std::min(2048, env_int("TSP_CLUSTER_MAX_ROWS", C == 1 ? kClRows : std::max(kClRows, 8 * C))));
     // steps per launch: a time limit is honoured between launches (the reference checks it per sweep / per pair), so a
