@@ -575,11 +575,15 @@ __global__ __launch_bounds__(64) void k_construct_nn_big(const CT *__restrict__ 
 // with one 16-byte (int32) or two 16-byte (double) non-temporal stores: a wave writes 1 KiB / 2 KiB
 // contiguous per row.  The row's coordinates are wave-uniform (scalar loads).  Write-bandwidth
 // bound: 4 n^2 (int32) or 8 n^2 (double) bytes to HBM against 16 n bytes of coordinates.
-constexpr int kDmRows = 16;
+// rows per block: few -- measured on MI355X at n = 10 000 (400 / 800 MB written): int32 16 rows 4.9, 8 rows 5.5, 4 rows 5.8-6.2,
+// 2 rows 5.7, 1 row 3.6 TB/s; double 16 rows 5.2, 4 rows 5.5, 1 row 6.2 TB/s.  More, shorter blocks keep more rows' segments in
+// flight next to each other; below that the per-block column loads stop being amortised.
+template <typename OUT> constexpr int dm_rows() { return sizeof(OUT) == 4 ? 4 : 1; }
 
 template <int WT, bool INT, typename OUT>
 __global__ __launch_bounds__(256) void k_dist_matrix(const double2 *__restrict__ coord, int n, OUT *__restrict__ out) {
     constexpr bool I32 = sizeof(OUT) == 4;
+    constexpr int kDmRows = dm_rows<OUT>();
     const int i0 = blockIdx.y * kDmRows;
     const int base = blockIdx.x * 1024;
     if (base >= n) return;
@@ -769,7 +773,8 @@ int tsp_dev_dist_matrix(tsp_dev_inst *inst, void *out_host, int as_int32, float 
     hipEvent_t e0, e1;
     TSP_HIP_TRY(hipEventCreate(&e0));
     TSP_HIP_TRY(hipEventCreate(&e1));
-    const dim3 grid((n + 1023) / 1024, (n + kDmRows - 1) / kDmRows);
+    const int rows_per_block = as_int32 ? dm_rows<int>() : dm_rows<double>();
+    const dim3 grid((n + 1023) / 1024, (n + rows_per_block - 1) / rows_per_block);
     const int reps = out_host ? 1 : 10;  // timing-only calls: warm once, then average back-to-back launches
     float ms = 0.f;
     auto launch = [&]() {

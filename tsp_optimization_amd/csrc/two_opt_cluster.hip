@@ -364,6 +364,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 
     const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
     bool failed = false;
+    // the workgroup's share of the group-pair table never changes: when it fits one round of box tests (one entry per
+    // thread) it is read once, not once per step (a global load at the head of every step's critical path otherwise)
+    int tab_reg = -1;
+    if constexpr (SORTED) {
+        if (a.ntests <= kClThreads && tid < a.ntests) tab_reg = a.pairtab[(size_t)c * a.ntests + tid];
+    }
     // executed work, per wave (wave-uniform values): rows or row-lanes through tier 0, pairs queued for tier 1, delta
     // expressions, staged records; summed into the tour's control block at the end of the launch
     long long w_lane = 0, w_t1 = 0, w_ex = 0, w_st = 0;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 int kept = 0;
                 while (m0 < a.ntests && kept + kClThreads <= kClListCap) {
                     const int m = m0 + tid;
-                    const int e = m < a.ntests ? tab[m] : -1;
+                    const int e = a.ntests <= kClThreads ? tab_reg : (m < a.ntests ? tab[m] : -1);
                     bool surv = false;
                     if (e >= 0) {
                         const int r = e >> 16, cg = e & 0xffff;
