@@ -90,11 +90,13 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     out = MS.run_sharded(refine, 256, n, rank, world, device)
     t_all = wall(time.perf_counter() - t0)
     table = golden("oracle_vectors.json")["att532_multistart256"]
-    assert (out["cost"], out["start"]) == (28998, 122), out            # best true cost 28998 at start 122
-    assert fnv1a(out["tour"]) == table[122]["hash"], "winner's tour differs from the golden"
+    # checks are recorded, never raised: a rank that threw between two collectives would leave the others waiting
+    ok4 = (out["cost"], out["start"]) == (28998, 122)                  # best true cost 28998 at start 122
+    tour4 = fnv1a(out["tour"]) == table[122]["hash"]
     res["config4_att532_grasp256_2opt"] = {
         "starts": 256, "starts_per_rank": out["local_starts"], "wall_s": t_all, "refine_s_max_over_ranks": wall(out["seconds"]),
-        "best_true_cost": out["cost"], "best_start": out["start"], "winner_tour_matches_golden": True,
+        "best_true_cost": out["cost"], "best_start": out["start"], "reference_best": [28998, 122],
+        "winner_is_the_reference_winner": bool(ok4), "winner_tour_matches_golden": bool(tour4),
         "collectives": "all_reduce(MIN) int64 + broadcast 4n bytes" if world > 1 else "none (1 GPU)"}
     inst.close()
 
@@ -109,17 +111,19 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     t_all = wall(time.perf_counter() - t0)
     gold = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]["individuals"]
     best = min(gold, key=lambda r: (r["cost"], r["k"]))
-    assert (out["cost"], out["start"]) == (int(best["cost"]), best["k"]), (out["cost"], out["start"], best)
-    assert fnv1a(out["tour"]) == best["hash"], "winner's tour differs from the golden"
+    ok5 = (out["cost"], out["start"]) == (int(best["cost"]), best["k"])
+    tour5 = fnv1a(out["tour"]) == best["hash"]
     mine = MS.shard_starts(128, rank, world)
     ev = int(sum(x["evals"] for x in refine.stats))
-    assert all(int(refine.stats[i]["evals"]) == gold[k]["ev"] and int(refine.stats[i]["moves"]) == gold[k]["mv"]
-               for i, k in enumerate(mine)), "per-individual counters differ from the golden table"
+    local5 = all(int(refine.stats[i]["evals"]) == gold[k]["ev"] and int(refine.stats[i]["moves"]) == gold[k]["mv"]
+                 for i, k in enumerate(mine))
+    all5 = wall(0.0 if local5 else 1.0) == 0.0        # max over ranks of "some local individual differs"
     res["config5_rand5000_population128_2opt"] = {
         "individuals": 128, "individuals_per_rank": out["local_starts"], "wall_s": t_all,
         "refine_s_max_over_ranks": wall(out["seconds"]), "best_cost": out["cost"], "best_individual": out["start"],
-        "rank0_reference_equivalent_evals": ev, "all_local_individuals_match_golden_counters": True,
-        "winner_tour_matches_golden": True}
+        "golden_best": [int(best["cost"]), best["k"]], "rank0_reference_equivalent_evals": ev,
+        "winner_is_the_golden_winner": bool(ok5), "winner_tour_matches_golden": bool(tour5),
+        "every_individual_on_every_rank_matches_golden_counters": bool(all5)}
     inst.close()
     return res
 
@@ -185,7 +189,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
-        dist.init_process_group(backend="nccl", device_id=device)
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
     else:
         local_rank = 0
 
@@ -300,7 +305,6 @@ def main():
                                                            and st["evals"] == big["stats"]["evals"]
                                                            and st["moves"] == big["stats"]["moves"]),
                          "golden": "tests/golden/oracle_vectors_big.json (oracle: full CPU descent, 23 min)"}
-        assert out["parity"]["final_tour_matches_golden"], out["parity"]
 
     if rank == 0:
         # roofline of the dominant kernel of the timed region: one k_cluster_two_opt launch per descent, HIP events on the
@@ -391,6 +395,9 @@ def main():
 
     if not args.no_extras:
         out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device)
+        out["all_checks_ok"] = bool(out.get("parity", {}).get("final_tour_matches_golden", True) and
+                                    all(v for d in out["other_configs"].values() for k, v in d.items()
+                                        if k.startswith(("winner_", "every_"))))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = max(1, min(16, len(os.sched_getaffinity(0))))   # a 1-GPU box's CPU share
