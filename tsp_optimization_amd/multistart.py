@@ -110,6 +110,19 @@ def succ_to_perm(succ):
     return np.asarray(perm, dtype=np.int32)
 
 
+def succ_to_perm_batch(succ):
+    """The same walk for a batch [B, n] of successor lists, one vectorised step per tour position."""
+    succ = np.asarray(succ)
+    B, n = succ.shape
+    perm = np.zeros((B, n), dtype=np.int32)
+    rows = np.arange(B)
+    v = np.zeros(B, dtype=np.int64)
+    for k in range(1, n):
+        v = succ[rows, v]
+        perm[:, k] = v
+    return perm
+
+
 def perm_to_succ(perm):
     """Permutation -> successor list (from_chromosome_to_edges, src/genetic.c:33-42)."""
     perm = np.asarray(perm, dtype=np.int32)
@@ -161,7 +174,7 @@ def config4_refiner(E, inst, starts, stream):
         ids = list(ids)
         succ, obj, _ = inst.construct(E.GRASP, starts[ids], stream[ids])
         rc, s2, o2, st = inst.two_opt(succ, obj, mode=E.FIRST)
-        true_cost = inst.perm_cost(np.stack([succ_to_perm(s) for s in s2]))
+        true_cost = inst.perm_cost(succ_to_perm_batch(s2))
         refine.stats = st
         return true_cost, s2
     return refine
@@ -173,7 +186,8 @@ def config5_refiner(E, inst, perms):
     def refine(ids):
         ids = list(ids)
         p = perms[ids]
-        succ = np.stack([perm_to_succ(x) for x in p])
+        succ = np.empty_like(p)
+        np.put_along_axis(succ, p, np.roll(p, -1, axis=1), axis=1)          # perm_to_succ for the whole shard
         cost = inst.perm_cost(p)
         rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST)
         refine.stats = st
