@@ -25,3 +25,6 @@ steps = max(1, buf[7])
 print("rand5000 random individual, LDS engine: %d steps, %d moves, device %.1f ms -> %.2f us/step" % (steps, st[0]["moves"], st[0]["device_ms"], 1e3 * st[0]["device_ms"] / steps))
 for k in range(4):
     print("  %-16s %8.0f cycles/step" % (names[k], buf[k] / steps))
+print("  tour 0: pairs scanned %d = %.0f per step = %.1f batches of 512 columns; reference evaluations %d = %.0f per move"
+      % (st[0]["pairs_scanned"], st[0]["pairs_scanned"] / st[0]["steps"], st[0]["pairs_scanned"] / st[0]["steps"] / 512.0,
+         st[0]["evals"], st[0]["evals"] / st[0]["moves"]))

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             // FIRST: the winner is the smallest key, and a hit in the block's first row ends the search: no later
             // batch of columns can hold a smaller one (dense-improvement phases -- random individuals -- find it
             // in the first batch after the cursor), so batches are 512 columns there and the block votes after each
-            // (512 then 2048 was measured: no better).
-            constexpr int U = MODE == TSP_2OPT_FIRST ? 1 : 4;
+            // (512 then 2048 was measured: no better; two batches per vote: 3 % better on configs[3] and [4]).
+            constexpr int U = MODE == TSP_2OPT_FIRST ? 2 : 4;   // FIRST: 1024 columns per vote (measured: 1 -> 2: -3 %, 4: +2 %)
             // batches that hold no column above the rows (or, for the cursor's row alone, above the cursor) are skipped
             const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == ci) ? cj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
             const bool vote = n - jbase > 2 * kLdsThreads;   // a vote is a barrier: not for two batches
