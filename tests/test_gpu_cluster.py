@@ -141,6 +141,29 @@ def test_cluster_gives_up_cleanly_when_a_cluster_cannot_be_resident(eng, ctx, mo
     inst.close()
 
 
+def test_cluster_gives_up_and_the_descent_is_redone_on_the_grid_engine(eng, ctx, monkeypatch):
+    """The exchange needs every workgroup of a cluster on the chip.  With the residency check lifted, two rand10000 tours
+    (one workgroup per CU at this size) get 200 workgroups each: the second cluster's first 56 workgroups are resident, the
+    other 144 wait for a CU until the first tour's descent is over (milliseconds); with the spin bound shortened the 56 give up
+    first, raise the error word and leave -- no hang --, and tsp_dev_two_opt redoes the batch on the GRID engine from the
+    untouched tours: results equal the goldens all the same."""
+    monkeypatch.setenv("TSP_CLUSTER_BLOCKS", "200")
+    monkeypatch.setenv("TSP_CLUSTER_ALLOW_OVERSUB", "1")
+    monkeypatch.setenv("TSP_CLUSTER_SPIN_LIMIT", "300")
+    xy, wt = load_instance("rand10000")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    succ = np.stack([succ0, succ0])
+    rc, s, o, st = inst.two_opt(succ, np.array([obj0, obj0]), mode=eng.FIRST, engine=eng.ENGINE_CLUSTER)
+    inst.close()
+    ref = APB["rand10000"]["first"]
+    assert rc == 0
+    for b in range(2):
+        assert o[b] == ref["cost"] and (st[b]["sweeps"], st[b]["evals"], st[b]["moves"]) == (ref["sw"], ref["ev"], ref["mv"])
+    assert (s[0] == s[1]).all() and O.is_tour(s[0])
+    assert b"not resident" in eng.lib().tsp_dev_last_error()      # the give-up was taken, not avoided
+
+
 # ---- drivers on resident tours: the kicks of tabu() and HEU_VNS on the device --------------------------------------
 def test_resident_tabu_iterations_equal_oracle(eng, ctx):
     """tabusearch.c:238-309 through the resident-tour API: alg_2opt_tabu on the device-resident tour with device-resident
