@@ -550,63 +550,41 @@ static void orc_ga_select_parents(orc_individual *population, int *parents, cons
     free(visited);
 }
 
-/* genetic.c:143-229 */
+/* genetic.c:143-229: method 1 (prefix of the first parent, the rest in the second parent's order; never drawn with the
+ * reference's CROSSOVER_METHOD_RATE 0.0) or method 2 (a window of the first parent kept in place, the other positions
+ * filled cyclically from the position after the window with the second parent's genes in its own cyclic order) */
 static void orc_ga_crossover(const orc_ga_ctx *g, const orc_individual *population, const int parent1, const int parent2,
-                             int *chromosome) {
-    orc_individual p1 = population[parent1];
-    orc_individual p2 = population[parent2];
+                             int *child) {
+    const int *mum = population[parent1].chromosome, *dad = population[parent2].chromosome;
     const int nn = g->num_nodes;
-    int *visited = calloc((size_t)nn, sizeof(int));
-    double rand_num = orc_urand();
-    if (rand_num < 0.0 /* CROSSOVER_METHOD_RATE, :17 */) {
-        int rand_index = orc_ga_rand_choice(0, nn);
-        int idx = 0;
-        for (int i = 0; i < nn; i++) {
-            if (i <= rand_index) {
-                int node = p1.chromosome[i];
-                visited[node] = 1;
-                chromosome[idx] = node;
-            } else {
-                int node = p2.chromosome[i];
-                if (visited[node]) { continue; }
-                chromosome[idx] = node;
-            }
-            idx++;
+    char *used = calloc((size_t)nn, 1);
+    const double method_draw = orc_urand();                                    /* :148 */
+    if (method_draw < 0.0 /* CROSSOVER_METHOD_RATE, :17 */) {
+        const int cut = orc_ga_rand_choice(0, nn);                             /* :152 */
+        int filled = 0;
+        for (int k = 0; k < nn; k++) {                                         /* :154-165 */
+            const int gene = k <= cut ? mum[k] : dad[k];
+            if (k > cut && used[gene]) continue;
+            if (k <= cut) used[gene] = 1;
+            child[filled++] = gene;
         }
-        if (idx < nn) {
-            for (int i = 0; i <= rand_index; i++) {
-                int node = p2.chromosome[i];
-                if (visited[node]) { continue; }
-                chromosome[idx++] = node;
-            }
-        }
+        for (int k = 0; filled < nn && k <= cut; k++)                          /* :167-173 */
+            if (!used[dad[k]]) child[filled++] = dad[k];
     } else {
-        int rand_index1 = orc_ga_rand_choice(0, nn);
-        int rand_index2 = orc_ga_rand_choice(0, nn);
-        if (rand_index1 > rand_index2) { int tmp = rand_index1; rand_index1 = rand_index2; rand_index2 = tmp; }
-        if (rand_index1 == rand_index2) {
-            if (rand_index1 > 0) rand_index1 -= 1; else rand_index2 += 1;
-        }
-        int nodes_added = 0;
-        for (int i = rand_index1; i <= rand_index2; i++) {
-            int node = p1.chromosome[i];
-            visited[node] = 1;
-            chromosome[i] = node;
-            nodes_added++;
-        }
-        int parent2_counter = rand_index2 + 1;
-        int offspring_crom_counter = parent2_counter;
-        while (nodes_added < nn) {
-            int node = p2.chromosome[parent2_counter % nn];
-            if (!visited[node]) {
-                chromosome[offspring_crom_counter % nn] = node;
-                nodes_added++;
-                offspring_crom_counter++;
-            }
-            parent2_counter++;
+        int lo = orc_ga_rand_choice(0, nn), hi = orc_ga_rand_choice(0, nn);    /* :180-181 */
+        if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+        if (lo == hi) { if (lo > 0) lo--; else hi++; }                         /* :187-193 */
+        int placed = hi - lo + 1;
+        for (int k = lo; k <= hi; k++) { child[k] = mum[k]; used[mum[k]] = 1; }    /* :196-201 */
+        for (long from = hi + 1, to = hi + 1; placed < nn; from++) {           /* :210-223: both counters run past nn, taken modulo */
+            const int gene = dad[from % nn];
+            if (used[gene]) continue;
+            child[to % nn] = gene;
+            to++;
+            placed++;
         }
     }
-    free(visited);
+    free(used);
 }
 
 /* genetic.c:240-256 */
@@ -673,21 +651,13 @@ static void orc_ga_mutation(const orc_ga_ctx *g, orc_individual *offsprings, con
         if (rand_mut < 0.1 /* MUTATION_RATE, :13 */) {
             double rand_method = orc_urand();
             if (rand_method > g->two_opt_prob) {
-                int rand_index1 = orc_ga_rand_choice(0, nn - 1);
-                int rand_index2 = orc_ga_rand_choice(0, nn - 1);
-                if (rand_index1 > rand_index2) { int tmp = rand_index1; rand_index1 = rand_index2; rand_index2 = tmp; }
-                if (rand_index1 == rand_index2) {
-                    if (rand_index1 > 0) rand_index1 -= 1; else rand_index2 += 1;
-                }
-                int tot_iter = rand_index2 - rand_index1;
-                int incr_idx = rand_index1;
-                int decr_idx = rand_index2;
-                for (int i = 0; i < tot_iter / 2; i++) {
-                    int tmp = offsprings[off].chromosome[incr_idx];
-                    offsprings[off].chromosome[incr_idx] = offsprings[off].chromosome[decr_idx];
-                    offsprings[off].chromosome[decr_idx] = tmp;
-                    incr_idx++;
-                    decr_idx--;
+                /* method 2, :400-424: the window [lo, hi] of the chromosome is reversed by (hi - lo) / 2 swaps from its ends */
+                int lo = orc_ga_rand_choice(0, nn - 1), hi = orc_ga_rand_choice(0, nn - 1);
+                if (lo > hi) { const int t = lo; lo = hi; hi = t; }
+                if (lo == hi) { if (lo > 0) lo--; else hi++; }
+                int *genes = offsprings[off].chromosome;
+                for (int swaps = (hi - lo) / 2, left = lo, right = hi; swaps > 0; swaps--, left++, right--) {
+                    const int t = genes[left]; genes[left] = genes[right]; genes[right] = t;
                 }
             } else {
                 /* :426-443: copy_instance, from_chromosome_to_edges, alg_2opt (obj_best = the instance's, whatever it is:
