@@ -12,12 +12,15 @@
 // Selection rules and semantics are those of the other engines (two_opt_grid.hip header): FIRST = alg_2opt
 // (src/heuristics.c:438-502), BEST = alg_2opt_tabu with skip_edge == NULL (src/tabusearch.c:107-178).
 // Two scans:
-//   tiles   every pair of the scanned rows visited, 32 rows x 512 columns per tile, tiles dealt round-robin to the
-//           cluster's workgroups (FIRST on any metric; BEST on metrics without the new-edge bound);
+//   tiles   every pair of the scanned rows visited, tiles of up to 32 rows x 512 columns dealt round-robin to the
+//           cluster's workgroups, the rows per tile shrinking until every workgroup has one (FIRST on any metric;
+//           BEST on metrics without the new-edge bound);
 //   sorted  BEST on sqrt metrics: nodes renumbered along the Hilbert curve (tsp_dev_inst_create), 64 consecutive
-//           ranks = one group; the box form of the new-edge bound decides 64 x 64 pairs at once, the surviving
-//           group pairs (host-built table, nearest first, dealt round-robin) go through row culling and the
-//           per-pair tiers exactly as in two_opt_sweep.hpp.  Group bound: gmax2[g] = longest tour edge INCIDENT to a
+//           ranks = one group; the box form of the new-edge bound decides 64 x 64 pairs at once.  The surviving
+//           group pairs (host-built table, nearest first, dealt round-robin) are staged eight at a time (their node
+//           records derived once into LDS, rows culled against the column box in the same pass), the live rows go
+//           four at a time through an fp32 tier 0, and the pairs that survive it are queued per wave and taken
+//           through tiers 1 and 2 sixty-four at a time.  Group bound: gmax2[g] = longest tour edge INCIDENT to a
 //           node of g (either direction), which a move changes for at most four groups -- no O(n) rebuild per step.
 // Residency: the cluster protocol needs all B C workgroups on the chip at once; the host launches at most one per CU
 // and every spin is bounded (a workgroup that gives up raises `err`, everybody leaves, the host falls back to GRID).
