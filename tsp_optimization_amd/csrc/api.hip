@@ -404,18 +404,19 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         //    tour, whole descent in one launch -- first improvement on any metric, best improvement where the sorted
         //    scan applies.  A step costs one exchange through L2 instead of one or two kernel boundaries.
         //  * LDS (one workgroup per tour): first-improvement batches of at least as many tours as half the CUs.
-        //  * GRID: everything else (tours beyond LDS, tabu runs, best improvement on metrics without the new-edge bound).
+        //  * GRID: everything else (tours beyond LDS, tabu runs, best-improvement batches).
         const char *force = getenv("TSP_ENGINE");
         const bool lds_ok = tsp_lds_fits(inst);
         const int C = tsp_cluster_fits(t, mode) ? tsp_cluster_size(t, mode) : 0;
-        const bool cl_mode_ok = mode == TSP_2OPT_FIRST || tsp_cluster_sorted(t, mode);
+        const bool cl_mode_ok = true;   // both rules, sorted or tiles scan (measured faster than GRID from n = 532 to 10 000, tools/cluster_time.py)
         bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
         // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
         const bool small_single = lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299;
         if (small_single) lds = true;
         // first improvement: many workgroups only pay where the scan, not the per-move latency, dominates or CUs would idle;
         // eight or more tours go one workgroup per tour (LDS) unless that would leave most of the chip idle
-        bool cluster = cl_mode_ok && !small_single && (mode == TSP_2OPT_BEST ? C >= 4 : (C >= 4 && (B < 8 || C >= 8)));
+        bool cluster = cl_mode_ok && !small_single &&
+                       (mode == TSP_2OPT_BEST ? (C >= 4 && (B < 8 || tsp_cluster_sorted(t, mode))) : (C >= 4 && (B < 8 || C >= 8)));
         if (force && *force == '1') { lds = false; cluster = false; }
         if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
         if (force && *force == '3' && C >= 1) cluster = true;
@@ -461,8 +462,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
 static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const bool want = engine == TSP_ENGINE_CLUSTER ||
-                          (tsp_cluster_fits(t, mode) && tsp_cluster_size(t, mode) >= 4 &&
-                           (mode == TSP_2OPT_FIRST || tsp_cluster_sorted(t, mode)));
+                          (tsp_cluster_fits(t, mode) && tsp_cluster_size(t, mode) >= 4);
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
             int fell = 0;
