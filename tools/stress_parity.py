@@ -19,6 +19,7 @@ import time
 for c in range(cases):
     t_case = time.perf_counter()
     n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(4, 600))
+    if rng.random() < 0.06: n = int(rng.integers(1000, 3000))   # a few larger ones (first improvement only on the CPU side)
     wt = int(rng.choice([O.EUC_2D, O.ATT, O.CEIL_2D, O.MAN_2D, O.MAX_2D]))
     ic = int(rng.random() < 0.75)
     int_coords = rng.random() < 0.5
@@ -58,9 +59,13 @@ for c in range(cases):
         t3 = np.stack([random_tour(n, rng) for _ in range(3)])
         c3 = np.array([O.succ_cost(xy, wt, t, integer_cost=ic) for t in t3])
         rc, s3, o3, st3 = inst.two_opt(t3, c3, mode=E.FIRST)
+        os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 7, 33, 85])))
+        rc, s4, o4, st4 = inst.two_opt(t3, c3, mode=E.FIRST, engine=3)      # three clusters side by side
+        del os.environ["TSP_CLUSTER_BLOCKS"]
         for b in range(3):
             _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
             ok = ok and (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"]
+            ok = ok and (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"]
         O.srandom(1000 + c)
         ur = np.array([[O.urand() for _ in range(n)]])
         O.srandom(1000 + c)
