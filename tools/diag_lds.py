@@ -18,6 +18,9 @@ rng = MS.LibcRandom(123)
 perms = np.stack([rng.random_perm(5000) for _ in range(16)])
 succ = np.stack([MS.perm_to_succ(p) for p in perms])
 cost = inst.perm_cost(perms)
+sb = (C.c_ulonglong * 8)()
+L.tsp_dev_debug_lds_scan.argtypes = [C.POINTER(C.c_ulonglong)]
+L.tsp_dev_debug_lds_scan(sb)
 L.tsp_dev_debug_lds(buf)
 rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST, engine=E.ENGINE_LDS)
 L.tsp_dev_debug_lds(buf)
@@ -25,6 +28,9 @@ steps = max(1, buf[7])
 print("rand5000 random individual, LDS engine: %d steps, %d moves, device %.1f ms -> %.2f us/step" % (steps, st[0]["moves"], st[0]["device_ms"], 1e3 * st[0]["device_ms"] / steps))
 for k in range(4):
     print("  %-16s %8.0f cycles/step" % (names[k], buf[k] / steps))
+L.tsp_dev_debug_lds_scan(sb)
+nbt = max(1, sb[3])
+print("  scan, per batch of columns (%.1f batches per step, %.2f rows each): column records %.0f cycles, row loop %.0f, vote %.0f" % (sb[3] / steps, sb[4] / nbt, sb[0] / nbt, sb[1] / nbt, sb[2] / nbt))
 print("  tour 0: pairs scanned %d = %.0f per step = %.1f batches of 512 columns; reference evaluations %d = %.0f per move"
       % (st[0]["pairs_scanned"], st[0]["pairs_scanned"] / st[0]["steps"], st[0]["pairs_scanned"] / st[0]["steps"] / 512.0,
          st[0]["evals"], st[0]["evals"] / st[0]["moves"]))

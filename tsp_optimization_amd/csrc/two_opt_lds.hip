@@ -21,7 +21,8 @@
 namespace tsp {
 
 #ifdef TSP_STAMPS
-__device__ unsigned long long g_lds_prof[8];   // tour 0, thread 0: cycles in scan / arg-min / counters / move / control, steps
+__device__ unsigned long long g_lds_prof[8];
+__device__ unsigned long long g_lds_scan[8];   // tour 0, thread 0: cycles deriving column records / in the row loop / in votes, batches, row iterations   // tour 0, thread 0: cycles in scan / arg-min / counters / move / control, steps
 #define LDS_T(k) do { const unsigned long long t_ = clock64(); prof[k] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define LDS_T(k) do { } while (0)
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
 
 #ifdef TSP_STAMPS
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+    unsigned long long scn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int iter = 0; iter < max_iters && !done; ++iter) {
         int row_lo = 0, row_hi = n - 1;
@@ -131,6 +133,9 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == ci) ? cj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
             const bool vote = n - jbase > 2 * kLdsThreads;   // a vote is a barrier: not for two batches
             for (int j0 = jbase + tid; j0 - tid < n; j0 += U * kLdsThreads) {
+#ifdef TSP_STAMPS
+                const unsigned long long q0 = clock64();
+#endif
                 int jj[U], pp[U], sc[U];
                 bool act[U];
                 double2 cxy[U], cs[U];
@@ -151,6 +156,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 }
 #pragma unroll
                 for (int k = 0; k < U; ++k) cs[k] = coord[sc[k]];
+#ifdef TSP_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long q1 = clock64();
+#endif
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     if (!act[k]) continue;
@@ -188,9 +197,17 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                         }
                     }
                 }
+#ifdef TSP_STAMPS
+                const unsigned long long q2 = clock64();
+                bool stop = false;
+                if constexpr (MODE == TSP_2OPT_FIRST) { if (vote) stop = __syncthreads_or(key != kNoKey && key_i(key) == rb); }
+                if (tour == 0 && tid == 0) { const unsigned long long q3 = clock64(); scn[0] += q1 - q0; scn[1] += q2 - q1; scn[2] += q3 - q2; scn[3] += 1; scn[4] += nr; }
+                if (stop) break;
+#else
                 if constexpr (MODE == TSP_2OPT_FIRST) {
                     if (vote && __syncthreads_or(key != kNoKey && key_i(key) == rb)) break;
                 }
+#endif
             }
         }
         LDS_T(0);
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     }
 
 #ifdef TSP_STAMPS
-    if (tour == 0 && tid == 0) { for (int k = 0; k < 4; ++k) g_lds_prof[k] += prof[k]; g_lds_prof[7] += steps - st->steps; }
+    if (tour == 0 && tid == 0) { for (int k = 0; k < 4; ++k) g_lds_prof[k] += prof[k]; g_lds_prof[7] += steps - st->steps; for (int k = 0; k < 5; ++k) g_lds_scan[k] += scn[k]; }
 #endif
     // ---- write back ---------------------------------------------------------------------------------------
     __syncthreads();
@@ -361,6 +378,12 @@ extern "C" int tsp_dev_debug_lds(unsigned long long *out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_lds_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_lds_prof), z, sizeof z);
+    return 0;
+}
+extern "C" int tsp_dev_debug_lds_scan(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_lds_scan), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_lds_scan), z, sizeof z);
     return 0;
 }
 #endif
