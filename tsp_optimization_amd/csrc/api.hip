@@ -399,24 +399,20 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         cluster_C = tsp_cluster_size(t, mode);
     }
     if (engine == TSP_ENGINE_AUTO) {
-        // Measured on MI355X (tools/gpu_latency.py, tools/gpu_configs.py, tools/cluster_time.py).  Results are identical.
+        // Measured on MI355X (tools/cluster_time.py, tools/shard_time.py).  Results are identical.
         //  * CLUSTER: tours that fit in a CU's LDS and leave CUs idle (B tours on 256 CUs): C = #CUs / B workgroups per
-        //    tour, whole descent in one launch -- first improvement on any metric, best improvement where the sorted
-        //    scan applies.  A step costs one exchange through L2 instead of one or two kernel boundaries.
-        //  * LDS (one workgroup per tour): first-improvement batches of at least as many tours as half the CUs.
-        //  * GRID: everything else (tours beyond LDS, tabu runs, best-improvement batches).
+        //    tour, whole descent in one launch.  A step costs one exchange through L2 instead of one or two kernel boundaries.
+        //  * LDS (one workgroup per tour): first-improvement batches of more tours than an eighth of the CUs.
+        //  * GRID: everything else (tours beyond LDS, tabu runs, large best-improvement batches).
         const char *force = getenv("TSP_ENGINE");
         const bool lds_ok = tsp_lds_fits(inst);
         const int C = tsp_cluster_fits(t, mode) ? tsp_cluster_size(t, mode) : 0;
-        const bool cl_mode_ok = true;   // both rules, sorted or tiles scan (measured faster than GRID from n = 532 to 10 000, tools/cluster_time.py)
         bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
-        // a single small tour on a sqrt metric: the whole descent in one launch beats ~10 us per step
-        const bool small_single = lds_ok && mode == TSP_2OPT_FIRST && B < 8 && inst->n <= 320 && inst->prune_margin < 1e299;
-        if (small_single) lds = true;
-        // first improvement: many workgroups only pay where the scan, not the per-move latency, dominates or CUs would idle;
-        // eight or more tours go one workgroup per tour (LDS) unless that would leave most of the chip idle
-        bool cluster = cl_mode_ok && !small_single &&
-                       (mode == TSP_2OPT_BEST ? (C >= 4 && (B < 8 || tsp_cluster_sorted(t, mode))) : (C >= 4 && (B < 8 || C >= 8)));
+        // few tours: CLUSTER whatever the cluster size (measured on single tours from berlin52 to rand10000, tools/cluster_time.py:
+        // 1.4-2.6 x faster than GRID in both rules, level with LDS at n = 52, 1.6 x faster at n = 299); eight or more tours: one
+        // workgroup per tour (LDS, first improvement) unless that would leave most of the chip idle (C >= 8), best-improvement
+        // batches on CLUSTER only with the sorted scan
+        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? (C >= 4 && tsp_cluster_sorted(t, mode)) : C >= 8));
         if (force && *force == '1') { lds = false; cluster = false; }
         if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
         if (force && *force == '3' && C >= 1) cluster = true;
@@ -462,7 +458,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
 static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const bool want = engine == TSP_ENGINE_CLUSTER ||
-                          (tsp_cluster_fits(t, mode) && tsp_cluster_size(t, mode) >= 4);
+                          (tsp_cluster_fits(t, mode) && (t->B < 8 || tsp_cluster_size(t, mode) >= 8));
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
             int fell = 0;
