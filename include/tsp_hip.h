@@ -155,6 +155,11 @@ int tsp_dev_tabu_set(tsp_dev_tabu *tabu, const int *idx, const int *value, int c
 int tsp_dev_tabu_get(tsp_dev_tabu *tabu, const int *idx, int *value, int count);
 int tsp_dev_tabu_upload(tsp_dev_tabu *tabu, const int *stamps);   /* n(n-1)/2 ints */
 int tsp_dev_tabu_download(tsp_dev_tabu *tabu, int *stamps);
+/* Diagnostics of the handle's compact list of non-zero stamps, from which runs with a list work (a few hundred entries
+ * of the reference's n(n-1)/2, :195): *entries = upper bound of its length, or -1 while it is out of date (the host
+ * wrote stamps; the next run scans); *used_by_last_run = 1 when the last alg_2opt_tabu call worked from the list, 0
+ * when it read the stamps pair by pair (list too long, tour outside the sorted sweep).  Either may be NULL. */
+int tsp_dev_tabu_list_info(tsp_dev_tabu *tabu, int *entries, int *used_by_last_run);
 /* One call of alg_2opt_tabu(inst, skip_edge, stored_prev, iter, tenure) on one tour.
  * stored_prev (may be NULL) receives the predecessor array (:173-175). */
 int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int tenure, int *succ,

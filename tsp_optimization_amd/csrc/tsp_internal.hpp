@@ -95,6 +95,16 @@ struct tsp_dev_tabu {
     tsp_dev_inst *inst = nullptr;
     long long count = 0;
     int *d_stamp = nullptr;
+    // compact list of the non-zero stamps (two_opt_tabu_list.hpp): what a sweep with a list works from
+    int2 *d_list = nullptr;
+    int *d_list_n = nullptr;                     // entries (device); may exceed list_cap after a scan = unusable
+    unsigned long long *d_tabu_pairs = nullptr;  // pairs the sweeps of the current run skipped as tabu
+    int *h_list_n = nullptr;                     // pinned
+    int list_cap = 0;
+    bool list_valid = false;                     // the list covers every non-zero stamp
+    long long list_ub = 0;                       // host's upper bound of the entry count
+    long long list_compact_at = 0;               // compaction when list_ub passes this
+    bool last_run_list = false;                  // the last run with this handle worked from the list
 };
 
 struct tsp_dev_tours {
@@ -133,6 +143,7 @@ struct tsp_dev_tours {
     std::vector<double> h_obj_snap;
     int *d_kick_result = nullptr;
     int *h_kick_result = nullptr;    // pinned
+    bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;
     std::vector<double> h_obj0;

@@ -65,9 +65,11 @@ __global__ void k_rearm(TourState *states, int B, int first_chunk) {
 // the reference's order, lazy clears included (:83-92, :282-285); if every edge is free the 2-exchange is carried out
 // (edges[a].j = b, edges[a1].j = b1, reverse_path(b, a1): positions pos[a]+1 .. pos[b] reversed) and the two removed edges
 // are stamped with iter (:306-309 -- the policy update in between does not read them).  result = {accepted, a1, b1, 0}.
+// list != nullptr: the handle's list of non-zero stamps is current; the two stamped edges join it unless they are in it
+// already (as entries whose stamp had been cleared).
 __global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *pos, int *stamp, int n, int a, int b, int iter,
-                                                             int tenure, int *result) {
-    __shared__ int s_acc, s_pa, s_pb;
+                                                             int tenure, int *result, int2 *list, int *list_n, int list_cap) {
+    __shared__ int s_acc, s_pa, s_pb, s_a1, s_b1, s_have[2];
     const int tid = threadIdx.x;
     if (tid == 0) {
         const int pa = pos[a], pb = pos[b];
@@ -79,10 +81,26 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *po
             if (acc) { stamp[udir_pos(a, a1, n)] = iter; stamp[udir_pos(b, b1, n)] = iter; }
         }
         result[0] = acc; result[1] = a1; result[2] = b1; result[3] = 0;
-        s_acc = acc; s_pa = pa; s_pb = pb;
+        s_acc = acc; s_pa = pa; s_pb = pb; s_a1 = a1; s_b1 = b1; s_have[0] = 0; s_have[1] = 0;
     }
     __syncthreads();
     if (!s_acc) return;
+    if (list && iter != 0) {   // a stamp of value 0 is no entry
+        const int e0x = min(a, s_a1), e0y = max(a, s_a1), e1x = min(b, s_b1), e1y = max(b, s_b1);
+        const int m = min(*list_n, list_cap);
+        for (int k = tid; k < m; k += kApplyThreads) {
+            const int2 e = list[k];
+            if (e.x == e0x && e.y == e0y) s_have[0] = 1;
+            if (e.x == e1x && e.y == e1y) s_have[1] = 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = *list_n;   // past list_cap the count keeps running and the host stops using the list
+            if (!s_have[0]) { if (k < list_cap) list[k] = make_int2(e0x, e0y); ++k; }
+            if (!s_have[1] && !(e0x == e1x && e0y == e1y)) { if (k < list_cap) list[k] = make_int2(e1x, e1y); ++k; }
+            *list_n = k;
+        }
+    }
     const int pa = s_pa, pb = s_pb;
     int L = pb - pa; if (L < 0) L += n;
     for (int t = tid; t < (L >> 1); t += kApplyThreads) {
@@ -145,6 +163,41 @@ bool sorted_sweep(const tsp_dev_tours *t) {
            t->inst->ng <= 32768;   // k_sweep packs (r, c) into one int and counts group pairs (ng (ng + 1) / 2) in an int
 }
 
+// This step of this run goes through k_move_recs + k_sweep (with a list: only when tabu_list_prepare said so)
+bool sorted_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
+    return mode == TSP_2OPT_BEST && sorted_sweep(t) && (!tabu || t->tabu_list_run);
+}
+
+constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: the dense scan (k_step<TABU>)
+
+// Before a run with a list: bring the handle's list of non-zero stamps up to date (a scan after the host wrote
+// stamps; a compaction once enough cleared entries have piled up) and say whether the run can work from it.
+int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
+    *usable = false;
+    if (!sorted_sweep(t) || t->B != 1 || !tb->d_list) return TSP_OK;
+    hipStream_t s = t->inst->ctx->stream;
+    bool readback = false;
+    if (!tb->list_valid) {
+        TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_tabu_scan, dim3(2048), dim3(256), 0, s, tb->d_stamp, tb->count, t->n, tb->d_list, tb->list_cap, tb->d_list_n);
+        readback = true;
+    } else if (tb->list_ub > tb->list_compact_at) {
+        hipLaunchKernelGGL(k_tabu_compact, dim3(1), dim3(1024), 0, s, tb->d_stamp, t->n, tb->d_list, tb->d_list_n);
+        readback = true;
+    }
+    if (readback) {
+        TSP_HIP_TRY(hipMemcpyAsync(tb->h_list_n, tb->d_list_n, sizeof(int), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        TSP_HIP_TRY(hipGetLastError());
+        const long long m = *tb->h_list_n;
+        tb->list_valid = m <= tb->list_cap;   // an overflowing scan leaves no list: the next run scans again
+        tb->list_ub = m;
+        tb->list_compact_at = m + 2048;
+    }
+    *usable = tb->list_valid && tb->list_ub <= kTabuListMax;
+    return TSP_OK;
+}
+
 // After sorted sweeps: pending move carried out, tour back in the first copy of order/pos.
 void launch_flush(tsp_dev_tours *t) {
     if (!t->d_order2) return;
@@ -180,6 +233,8 @@ StepArgs make_args(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int
     a.gbox = t->inst->d_gbox; a.gmax = t->d_gmax;
     a.ng = t->inst->ng; a.n_slots = t->inst->n_slots;
     a.flat_slots = t->sweep_blocks;
+    a.tabu_list = tabu ? tabu->d_list : nullptr; a.tabu_list_n = tabu ? tabu->d_list_n : nullptr;
+    a.tabu_list_cap = tabu ? tabu->list_cap : 0; a.tabu_pairs = tabu ? tabu->d_tabu_pairs : nullptr;
     return a;
 }
 
@@ -188,13 +243,16 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
     hipStream_t s = t->inst->ctx->stream;
     StepArgs a = make_args(t, mode, tabu, iter, tenure);
     if constexpr (has_root_filter<WT>()) {
-        if (mode == TSP_2OPT_BEST && !tabu && sorted_sweep(t)) {
+        if (sorted_run(t, mode, tabu)) {
             a.recs = t->d_rec;
             const int ns = t->inst->n_slots;
             hipLaunchKernelGGL((k_move_recs<WT, INT>), dim3((std::max(ns, t->n) + kScanThreads - 1) / kScanThreads, t->B),
                                dim3(kScanThreads), 0, s, t->inst->d_coord, t->d_order, t->d_pos, t->d_order2, t->d_pos2,
                                t->d_state, t->inst->d_sperm, t->d_rec, t->d_gmax, t->n, t->inst->ng, ns);
-            hipLaunchKernelGGL((k_sweep<WT, INT>), dim3(t->sweep_blocks, 1, t->B), dim3(kScanThreads), 0, s, a);
+            if (tabu)
+                hipLaunchKernelGGL((k_sweep<WT, INT, true>), dim3(t->sweep_blocks + kTabuSideBlocks, 1, t->B), dim3(kScanThreads), 0, s, a);
+            else
+                hipLaunchKernelGGL((k_sweep<WT, INT>), dim3(t->sweep_blocks, 1, t->B), dim3(kScanThreads), 0, s, a);
             return TSP_OK;
         }
     }
@@ -281,6 +339,16 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     if (!sync && max_steps < 0) return TSP_DEV_E_ARG;   // "until done" needs the polls of a synchronous run: it would queue launches forever
     hipStream_t s = t->inst->ctx->stream;
     const double t0 = wall_s();
+    if (tabu && (iter < 0 || tenure < 0)) tabu = nullptr;   // check_tenure answers 0 before it reads anything (tabusearch.c:84)
+    t->tabu_list_run = false;
+    if (tabu && mode == TSP_2OPT_BEST) {
+        bool usable = false;
+        const int rc = tabu_list_prepare(t, tabu, &usable);
+        if (rc) return rc;
+        t->tabu_list_run = usable && env_int("TSP_TABU_DENSE", 0) == 0;
+        tabu->last_run_list = t->tabu_list_run;
+        if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, sizeof(unsigned long long), s));
+    }
     const int64_t batch = 64;
     // launches between two looks at `done`: short descents (a kicked local optimum, a small instance) should not
     // pay for dozens of launches that find their tour finished, long ones not for many polls
@@ -329,7 +397,9 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         if (done) { finished = true; if (all_done) *all_done = 1; break; }
         if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
     }
-    if ((mode == TSP_2OPT_BEST && !tabu && sorted_sweep(t)) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
+    if (tabu && t->tabu_list_run)   // the sweeps counted every non-adjacent pair; the skipped ones come off
+        hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, s, t->d_state, tabu->d_tabu_pairs);
+    if (sorted_run(t, mode, tabu) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
         launch_flush(t);
         TSP_HIP_TRY(hipGetLastError());
         if (sync) TSP_HIP_TRY(hipStreamSynchronize(s));
@@ -380,10 +450,14 @@ int tsp_grid_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int i
     if (rc) return rc;
     hipStream_t s = t->inst->ctx->stream;
     hipLaunchKernelGGL(k_tabu_kick, dim3(1), dim3(kApplyThreads), 0, s, t->d_order, t->d_pos, tabu->d_stamp, t->n, a, b, iter,
-                       tenure, t->d_kick_result);
+                       tenure, t->d_kick_result, tabu->list_valid ? tabu->d_list : nullptr, tabu->d_list_n, tabu->list_cap);
     TSP_HIP_TRY(hipMemcpyAsync(t->h_kick_result, t->d_kick_result, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
+    if (t->h_kick_result[0] && tabu->list_valid) {
+        tabu->list_ub += 2;
+        if (tabu->list_ub > tabu->list_cap) tabu->list_valid = false;   // entries may have been dropped: scan before the next use
+    }
     if (accepted) *accepted = t->h_kick_result[0];
     return TSP_OK;
 }
@@ -710,9 +784,20 @@ int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out) {
     tsp_dev_tabu *tb = new tsp_dev_tabu();
     tb->inst = inst;
     tb->count = (long long)inst->n * (inst->n - 1) / 2;
-    TSP_HIP_TRY(hipMalloc(&tb->d_stamp, sizeof(int) * (size_t)tb->count));
+    struct Guard { tsp_dev_tabu *tb; ~Guard() { if (tb) tsp_dev_tabu_destroy(tb); } } guard{tb};
+    TSP_HIP_TRY(hipMalloc(&tb->d_stamp, sizeof(int) * (size_t)std::max<long long>(1, tb->count)));
     TSP_HIP_TRY(hipMemsetAsync(tb->d_stamp, 0, sizeof(int) * (size_t)tb->count, inst->ctx->stream));
+    tb->list_cap = (int)std::max<long long>(16, std::min<long long>(tb->count, 1ll << 18));
+    TSP_HIP_TRY(hipMalloc(&tb->d_list, sizeof(int2) * (size_t)tb->list_cap));
+    TSP_HIP_TRY(hipMalloc(&tb->d_list_n, sizeof(int)));
+    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, sizeof(unsigned long long)));
+    TSP_HIP_TRY(hipHostMalloc(&tb->h_list_n, sizeof(int)));
+    TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), inst->ctx->stream));
+    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, sizeof(unsigned long long), inst->ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(inst->ctx->stream));
+    tb->list_valid = true;   // no stamp is set: the empty list is complete
+    tb->list_ub = 0; tb->list_compact_at = 2048;
+    guard.tb = nullptr;
     *out = tb;
     return TSP_OK;
 }
@@ -721,7 +806,8 @@ void tsp_dev_tabu_destroy(tsp_dev_tabu *tb) {
     if (!tb) return;
     (void)hipSetDevice(tb->inst->ctx->device);
     (void)hipStreamSynchronize(tb->inst->ctx->stream);
-    (void)hipFree(tb->d_stamp);
+    (void)hipFree(tb->d_stamp); (void)hipFree(tb->d_list); (void)hipFree(tb->d_list_n); (void)hipFree(tb->d_tabu_pairs);
+    (void)hipHostFree(tb->h_list_n);
     delete tb;
 }
 
@@ -736,6 +822,7 @@ static int stamp_io(tsp_dev_tabu *tb, const int *idx, int *val, int count, bool 
     if (!d_idx) return TSP_DEV_E_NOMEM;
     TSP_HIP_TRY(hipMemcpyAsync(d_idx, idx, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
     if (scatter) {
+        tb->list_valid = false;   // the list of non-zero stamps is rebuilt by a scan before the next run
         TSP_HIP_TRY(hipMemcpyAsync(d_val, val, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_stamp_scatter, dim3((count + 255) / 256), dim3(256), 0, s, tb->d_stamp, d_idx, d_val, count);
     } else {
@@ -753,9 +840,16 @@ int tsp_dev_tabu_set(tsp_dev_tabu *tb, const int *idx, const int *value, int cou
 int tsp_dev_tabu_get(tsp_dev_tabu *tb, const int *idx, int *value, int count) {
     return stamp_io(tb, idx, value, count, false);
 }
+int tsp_dev_tabu_list_info(tsp_dev_tabu *tb, int *entries, int *used_by_last_run) {
+    if (!tb) return TSP_DEV_E_ARG;
+    if (entries) *entries = tb->list_valid ? (int)tb->list_ub : -1;
+    if (used_by_last_run) *used_by_last_run = tb->last_run_list ? 1 : 0;
+    return TSP_OK;
+}
 int tsp_dev_tabu_upload(tsp_dev_tabu *tb, const int *stamps) {
     if (!tb || !stamps) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(tb->inst->ctx->device));
+    tb->list_valid = false;
     TSP_HIP_TRY(hipMemcpyAsync(tb->d_stamp, stamps, sizeof(int) * (size_t)tb->count, hipMemcpyHostToDevice,
                                tb->inst->ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(tb->inst->ctx->stream));

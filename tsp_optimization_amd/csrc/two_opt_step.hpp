@@ -179,6 +179,11 @@ struct StepArgs {
     const double4 *gbox;
     const double *gmax;
     int ng, n_slots, flat_slots;
+    // k_sweep<TABU> (two_opt_tabu_list.hpp): the compact list of non-zero stamps and the sweep's skipped-pair counter
+    const int2 *tabu_list;
+    const int *tabu_list_n;
+    int tabu_list_cap;
+    unsigned long long *tabu_pairs;
 };
 
 template <int WT, bool INT, int MODE, int RJ, bool TABU, bool FLAT = false>

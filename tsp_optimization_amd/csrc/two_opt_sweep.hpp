@@ -2,6 +2,7 @@
 // Part of the GRID engine; included by two_opt_grid.hip only (one translation unit).
 #pragma once
 #include "two_opt_step.hpp"
+#include "two_opt_tabu_list.hpp"
 
 #pragma clang fp contract(off)
 
@@ -121,7 +122,9 @@ constexpr int kSweepListCap = 1024;   // survivors one block can hold (more are 
 // pair at a time against one column per lane: rows that cannot reach the column box are dropped by one ballot, the
 // others go four per step with their x, y, edge length broadcast out of registers (v_readlane), so the common path
 // (tier 0) touches neither memory nor LDS.  The waves of a block share nothing until the block's arg-min.
-template <int WT, bool INT>
+// TABU: a call with a tabu list (two_opt_tabu_list.hpp): a pair that would become a lane's best goes through the
+// reference's check_tenure chain first, and the workgroups past a.flat_slots reproduce the scan's side effects.
+template <int WT, bool INT, bool TABU = false>
 __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {   // 3 waves per SIMD: 768 blocks resident
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
     constexpr int NW = kScanThreads / 64;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
     const NodeRec *rec = a.recs + (size_t)tour * a.n_slots;
     const double *gmax = a.gmax + (size_t)tour * (ng + 1);
     const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
-    const int Q = (int)gridDim.x / kSweepCluster, q = (int)blockIdx.x / kSweepCluster, j = (int)blockIdx.x % kSweepCluster;
+    const int Q = a.flat_slots / kSweepCluster, q = (int)blockIdx.x / kSweepCluster, j = (int)blockIdx.x % kSweepCluster;
     const int npairs = ng * (ng + 1) / 2;
     const int ntests = (npairs + Q - 1) / Q;   // stride blocks of group pairs; the last one may be partial
 
@@ -146,6 +149,18 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
     __shared__ double s_cgmax[kSweepStage];
     __shared__ int s_list[kSweepListCap];   // r << 16 | c
     __shared__ int s_wcount[NW];
+    if constexpr (TABU) {
+        if ((int)blockIdx.x >= a.flat_slots) {
+            // k_move_recs has carried the pending move out: the other copy is the tour this sweep scans
+            const bool second = (st->parity ^ st->pending) != 0;
+            const size_t base = (size_t)tour * a.n;
+            const TabuTour tt{(second ? a.orders2 : a.orders) + base, (second ? a.poss2 : a.poss) + base, a.n};
+            const TabuView tv{a.tabu, a.n, a.iter, a.tenure};
+            tabu_side<kScanThreads>(reinterpret_cast<int *>(&s_stage[0][0]), tt, tv, a.tabu_list, min(*a.tabu_list_n, a.tabu_list_cap), (int)blockIdx.x - a.flat_slots,
+                                    (int)gridDim.x - a.flat_slots, a.tabu_pairs);
+            return;
+        }
+    }
     double bd = 0.0;
     u64 key = kNoKey;
 
@@ -289,7 +304,19 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
                             const double delta = (INT || ri[u].id < rj.id) ? pair_delta<WT, INT>(ri[u], rj)
                                                                             : pair_delta<WT, INT>(rj, ri[u]);
                             const u64 kk = make_key(min(ri[u].id, rj.id), max(ri[u].id, rj.id));
-                            if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) { bd = delta; key = kk; bound = bd; }
+                            if (delta < bd || (delta == bd && delta < 0.0 && kk < key)) {
+                                bool tabu = false;
+                                if constexpr (TABU) {   // tabusearch.c:137-149, a = the lower node id, lazy clears included
+                                    const bool row_lo = ri[u].id < rj.id;
+                                    const int i = row_lo ? ri[u].id : rj.id, jn = row_lo ? rj.id : ri[u].id;
+                                    const int a1 = row_lo ? ri[u].succ : rj.succ, b1 = row_lo ? rj.succ : ri[u].succ;
+                                    tabu = stamp_is_tabu(a.tabu + udir_pos(i, jn, a.n), a.iter, a.tenure) ||
+                                           stamp_is_tabu(a.tabu + udir_pos(i, a1, a.n), a.iter, a.tenure) ||
+                                           stamp_is_tabu(a.tabu + udir_pos(jn, b1, a.n), a.iter, a.tenure) ||
+                                           stamp_is_tabu(a.tabu + udir_pos(i, b1, a.n), a.iter, a.tenure);
+                                }
+                                if (!tabu) { bd = delta; key = kk; bound = bd; }
+                            }
                         }
                     }
                 }

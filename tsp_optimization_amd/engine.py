@@ -67,6 +67,7 @@ def lib():
         L.tsp_dev_tabu_get.argtypes = [vp, ip, ip, C.c_int]
         L.tsp_dev_tabu_upload.argtypes = [vp, ip]
         L.tsp_dev_tabu_download.argtypes = [vp, ip]
+        L.tsp_dev_tabu_list_info.argtypes = [vp, ip, ip]
         L.tsp_dev_two_opt_tabu.argtypes = [vp, vp, C.c_int, C.c_int, ip, C.c_int, dp, ip, C.c_double, sp]
         L.tsp_dev_perm_cost.argtypes = [vp, C.c_int, ip, C.c_int64, dp]
         L.tsp_dev_tours_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
@@ -94,7 +95,7 @@ EXPORTED = [
     "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size",
     "tsp_dev_dist_pairs", "tsp_dev_selftest_raw_sqrt", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_extramileage", "tsp_dev_two_opt",
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
-    "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
+    "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
     "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_vns_kick",
@@ -275,6 +276,12 @@ class Tabu:
         out = np.zeros(n * (n - 1) // 2, dtype=np.int32)
         _check(lib().tsp_dev_tabu_download(self._h, _i(out)))
         return out
+
+    def list_info(self):
+        """-> (entries of the compact list of non-zero stamps or -1 while out of date, last run worked from the list)"""
+        e, u = C.c_int(0), C.c_int(0)
+        _check(lib().tsp_dev_tabu_list_info(self._h, C.byref(e), C.byref(u)))
+        return e.value, bool(u.value)
 
     def two_opt(self, succ, iter_, tenure, want_prev=False, time_limit=-1.0):
         """alg_2opt_tabu(inst, skip_edge, stored_prev, iter, tenure) -> (status, succ', obj', stats, prev)"""
