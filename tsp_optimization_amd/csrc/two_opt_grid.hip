@@ -158,14 +158,16 @@ dim3 scan_grid(const tsp_dev_tours *t) {
 int env_int(const char *name, int dflt);
 
 // BEST sweeps of this handle go through k_move_recs + k_sweep (no tabu list, metric with the new-edge bound)
-bool sorted_sweep(const tsp_dev_tours *t) {
-    return t->inst->d_sperm && t->d_gmax && t->d_order2 && t->n >= t->sorted_min_n && t->inst->prune_margin < 1e299 &&
+bool sorted_sweep_possible(const tsp_dev_tours *t) {
+    return t->inst->d_sperm && t->d_gmax && t->d_order2 && t->inst->prune_margin < 1e299 &&
            t->inst->ng <= 32768;   // k_sweep packs (r, c) into one int and counts group pairs (ng (ng + 1) / 2) in an int
 }
+bool sorted_sweep(const tsp_dev_tours *t) { return sorted_sweep_possible(t) && t->n >= t->sorted_min_n; }
 
 // This step of this run goes through k_move_recs + k_sweep (with a list: only when tabu_list_prepare said so)
 bool sorted_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
-    return mode == TSP_2OPT_BEST && sorted_sweep(t) && (!tabu || t->tabu_list_run);
+    if (mode != TSP_2OPT_BEST) return false;
+    return tabu ? t->tabu_list_run : sorted_sweep(t);
 }
 
 constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: the dense scan (k_step<TABU>)
@@ -174,7 +176,8 @@ constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: t
 // stamps; a compaction once enough cleared entries have piled up) and say whether the run can work from it.
 int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
     *usable = false;
-    if (!sorted_sweep(t) || t->B != 1 || !tb->d_list) return TSP_OK;
+    // any size: the alternative reads four stamps per pair (60 us per sweep at n = 299 against 19)
+    if (!sorted_sweep_possible(t) || t->B != 1 || !tb->d_list || t->n < 8) return TSP_OK;
     hipStream_t s = t->inst->ctx->stream;
     bool readback = false;
     if (!tb->list_valid) {
@@ -347,7 +350,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         if (rc) return rc;
         t->tabu_list_run = usable && env_int("TSP_TABU_DENSE", 0) == 0;
         tabu->last_run_list = t->tabu_list_run;
-        if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, sizeof(unsigned long long), s));
+        if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
     }
     const int64_t batch = 64;
     // launches between two looks at `done`: short descents (a kicked local optimum, a small instance) should not
@@ -790,10 +793,10 @@ int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out) {
     tb->list_cap = (int)std::max<long long>(16, std::min<long long>(tb->count, 1ll << 18));
     TSP_HIP_TRY(hipMalloc(&tb->d_list, sizeof(int2) * (size_t)tb->list_cap));
     TSP_HIP_TRY(hipMalloc(&tb->d_list_n, sizeof(int)));
-    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, sizeof(unsigned long long)));
+    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, 4 * sizeof(unsigned long long)));
     TSP_HIP_TRY(hipHostMalloc(&tb->h_list_n, sizeof(int)));
     TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), inst->ctx->stream));
-    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, sizeof(unsigned long long), inst->ctx->stream));
+    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), inst->ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(inst->ctx->stream));
     tb->list_valid = true;   // no stamp is set: the empty list is complete
     tb->list_ub = 0; tb->list_compact_at = 2048;

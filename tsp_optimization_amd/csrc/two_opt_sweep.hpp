@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void k_sweep(const StepArgs a) {  
             const TabuTour tt{(second ? a.orders2 : a.orders) + base, (second ? a.poss2 : a.poss) + base, a.n};
             const TabuView tv{a.tabu, a.n, a.iter, a.tenure};
             tabu_side<kScanThreads>(reinterpret_cast<int *>(&s_stage[0][0]), tt, tv, a.tabu_list, min(*a.tabu_list_n, a.tabu_list_cap), (int)blockIdx.x - a.flat_slots,
-                                    (int)gridDim.x - a.flat_slots, a.tabu_pairs);
+                                    (int)gridDim.x - a.flat_slots, a.tabu_pairs);   // tabu_pairs: the handle's three side words
             return;
         }
     }

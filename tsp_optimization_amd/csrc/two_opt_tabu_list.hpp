@@ -19,7 +19,7 @@
 //            of a pair (a, x) whose first two pass, or the (a,b1) check of the pair (succ x, pred x);
 //   evals    non-adjacent pairs minus the skipped ones, the latter counted once each by the FIRST live check of the
 //            chain: P1 live (a,b); P2 live (a,a1) [rows of nodes whose tour edge is live]; P3 live (b,b1) [their
-//            columns]; P4 live (a,b1) [two pairs per live stamp].
+//            columns]; P4 live (a,b1) [two pairs per live stamp] -- O(1) per list entry, see tabu_side().
 // Nothing here changes a result: tests/test_gpu_tabu_list.py runs it against the oracle with dense random lists
 // (stamps on tour edges, live and expired) and compares tours, counters and the whole stamp array.
 #pragma once
@@ -84,10 +84,10 @@ __global__ __launch_bounds__(1024) void k_tabu_compact(const int *__restrict__ s
 }
 
 // after a run: evals counted every non-adjacent pair of every sweep; take the skipped ones off (tabusearch.c:150)
-__global__ void k_tabu_fix_evals(TourState *st, unsigned long long *tabu_pairs) {
+__global__ void k_tabu_fix_evals(TourState *st, unsigned long long *side) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        st->evals -= (long long)*tabu_pairs;
-        *tabu_pairs = 0ull;
+        st->evals -= (long long)side[0];
+        side[0] = 0ull;
     }
 }
 
@@ -122,65 +122,69 @@ __device__ inline bool tabu_edge_looked_at(const TabuTour &t, const TabuView &tv
     return false;
 }
 
-// scratch: NT + 2 + 2 * (NT / 64) ints of LDS, 8-byte aligned
+// One sweep's side effects.  Called by the nsb workgroups past the sweep's own; side[0] = skipped pairs of the run,
+// side[1] / side[2] = this sweep's count of live tour edges and the arrival ticket (both zero between launches).
+// With E = the live stamps on non-adjacent pairs (u < v), F = the nodes whose tour edge x -> succ x is live, and
+// f(v) = [v in F], the skipped pairs of a sweep are
+//   P1            |E|
+//   P2 + P3       |F| (n - 3)  -  sum_E f(u)  -  sum_E f(v)  +  sum_E f(u) f(v)  -  C(|F|, 2)  +  |{x in F : succ x in F}|
+//                 (rows and columns of the F nodes without the pairs an earlier check of the chain already skipped:
+//                 members of E in those rows / columns, pairs of two F nodes -- the adjacent ones were never pairs)
+//   P4            per live stamp (a, w) and orientation: the pair (a, pred w) if it is a pair (a < pred w, not adjacent)
+//                 whose three earlier checks are not live
+// scratch: 2 * (NT / 64) ints of LDS, 8-byte aligned.
 template <int NT>
 __device__ inline void tabu_side(int *scratch, const TabuTour t, const TabuView tv, const int2 *__restrict__ list, int m, int sb,
-                                 int nsb, unsigned long long *tabu_pairs) {
-    long long *s_sum = reinterpret_cast<long long *>(scratch);   // NT / 64
-    int *s_f = scratch + 2 * (NT / 64);   // nodes whose tour edge carries a live stamp, found in the current chunk
-    int &s_nf = scratch[2 * (NT / 64) + NT];
+                                 int nsb, unsigned long long *side) {
+    long long *s_sum = reinterpret_cast<long long *>(scratch);
     const int tid = threadIdx.x, n = t.n;
     long long cnt = 0;
-    for (int k0 = sb * NT; k0 < m; k0 += nsb * NT) {
-        if (tid == 0) s_nf = 0;
-        __syncthreads();
-        const int k = k0 + tid;
-        if (k < m) {
-            const int2 e = list[k];
-            const int u = e.x, v = e.y;
-            int *sp = tv.stamp + udir_pos(u, v, n);
-            const int s = *sp;
-            if (s != 0) {
-                const int su = t.succ(u), sv = t.succ(v);
-                const bool uv = su == v, vu = sv == u;   // the stamped edge is a tour edge u -> v / v -> u
-                if (!tv.live_value(s)) {
-                    // (tabusearch.c:87-90) cleared by the first look; a non-adjacent pair's own stamp is its first check
-                    if (!uv && !vu) *sp = 0;
-                    else if (tabu_edge_looked_at(t, tv, uv ? u : v, uv ? v : u)) *sp = 0;
-                } else {
-                    if (!uv && !vu) cnt += 1;   // P1: the pair (u, v) itself
-                    // P4: the stamp is (a, b1) of the pair (a, b = pred w), {a, w} = {u, v}; counted unless an
-                    // earlier check of the chain is live as well
+    int nf = 0;
+    for (int k = sb * NT + tid; k < m; k += nsb * NT) {
+        const int2 e = list[k];
+        const int u = e.x, v = e.y;
+        int *sp = tv.stamp + udir_pos(u, v, n);
+        const int s = *sp;
+        if (s == 0) continue;   // cleared since it joined the list
+        const int su = t.succ(u), sv = t.succ(v);
+        const bool uv = su == v, vu = sv == u;   // the stamped edge is a tour edge u -> v / v -> u
+        if (!tv.live_value(s)) {
+            // (tabusearch.c:87-90) cleared by the first look; a non-adjacent pair's own stamp is its first check
+            if (!uv && !vu) *sp = 0;
+            else if (tabu_edge_looked_at(t, tv, uv ? u : v, uv ? v : u)) *sp = 0;
+            continue;
+        }
+        if (!uv && !vu) {
+            const int fu = tv.live(u, su) ? 1 : 0, fv = tv.live(v, sv) ? 1 : 0;
+            cnt += 1 - fu - fv + fu * fv;
+        } else {
+            nf += 1;
+            cnt += n - 3;
+            const int y = uv ? v : u, sy = uv ? sv : su;
+            if (tv.live(y, sy)) cnt += 1;
+        }
+        // P4: the stamp is (a, b1) of the pair (a, b = pred w), {a, w} = {u, v}
 #pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        const int a = o ? v : u, w = o ? u : v;
-                        const int b = t.pred(w);
-                        if (b != a && a < b && b != (o ? sv : su) &&
-                            !tv.live(a, b) && !tv.live(a, o ? sv : su) && !tv.live(b, w))
-                            cnt += 1;
-                    }
-                    if (uv || vu) s_f[atomicAdd(&s_nf, 1)] = uv ? u : v;
-                }
-            }
+        for (int o = 0; o < 2; ++o) {
+            const int a = o ? v : u, w = o ? u : v, sa = o ? sv : su;
+            const int b = t.pred(w);
+            if (b != a && a < b && b != sa && !tv.live(a, b) && !tv.live(a, sa) && !tv.live(b, w)) cnt += 1;
         }
-        __syncthreads();
-        // P2 / P3: rows and columns of the nodes x whose tour edge x -> y is live, by the whole workgroup
-        const int nf = s_nf;
-        for (int f = 0; f < nf; ++f) {
-            const int x = s_f[f];
-            const int y = t.succ(x), px = t.pred(x);
-            for (int c = tid; c < n; c += NT) {
-                if (c == x || c == y || c == px) continue;   // adjacent pairs are never looked at (tabusearch.c:134)
-                bool skipped;
-                if (c > x) skipped = !tv.live(x, c);                                  // pair (x, c): (a,b) passes, (a,a1) is live
-                else skipped = !tv.live(c, x) && !tv.live(c, t.succ(c));              // pair (c, x): two checks pass, (b,b1) is live
-                cnt += skipped ? 1 : 0;
-            }
-        }
-        __syncthreads();
     }
     const long long tot = block_sum<long long>(cnt, s_sum);
-    if (tid == 0 && tot) atomicAdd(tabu_pairs, (unsigned long long)tot);
+    const long long totf = block_sum<long long>((long long)nf, s_sum);
+    if (tid == 0) {
+        if (tot) atomicAdd(side, (unsigned long long)tot);
+        if (totf) atomicAdd(side + 1, (unsigned long long)totf);
+        __threadfence();
+        if (atomicAdd(side + 2, 1ull) == (unsigned long long)(nsb - 1)) {   // the last of the side workgroups
+            __threadfence();
+            const long long f = (long long)atomicAdd(side + 1, 0ull);
+            atomicAdd(side, (unsigned long long)(-(f * (f - 1) / 2)));
+            atomicExch(side + 1, 0ull);
+            atomicExch(side + 2, 0ull);
+        }
+    }
 }
 
 }  // namespace tsp
