@@ -61,7 +61,8 @@ template <int WT, bool INT, int MODE, bool CACHE>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
-                                                             int rmax, int count_evals, int max_iters, double margin, double prune) {
+                                                             int rmax, int count_evals, int max_iters, double margin, double prune,
+                                                             int probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
     double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     u64 *s_k = reinterpret_cast<u64 *>(scratch + 128);            // 16
     long long *s_ll = reinterpret_cast<long long *>(scratch + 256);  // 16
     double *s_chunk = reinterpret_cast<double *>(scratch + 384);  // 64 doubles (fcost cost recompute)
+    int4 *s_win = reinterpret_cast<int4 *>(scratch + 384);        // 8 (FIRST, the probe's vote): shares the chunk, which only BEST uses
 
     const int tour = blockIdx.x;
     const int tid = threadIdx.x;
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     double obj = st->obj, seen = st->seen_cost;
     long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
               scanned = st->pairs_scanned, steps = st->steps;
+    long long adj_acc = 0;                      // this thread's share of the adjacent pairs the reference skipped (heuristics.c:471)
+    long long r_cur = pair_rank(ci, cj, n);     // rank of the cursor in scan order
     __syncthreads();
     if constexpr (CACHE) {
         for (int p = tid; p < n; p += kLdsThreads) {
@@ -110,13 +114,115 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     unsigned long long scn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int iter = 0; iter < max_iters && !done; ++iter) {
+        LDS_T(6);   // control block of the step before
         int row_lo = 0, row_hi = n - 1;
-        if constexpr (MODE == TSP_2OPT_FIRST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
-
-        // ---- scan ------------------------------------------------------------------------------
         double bd = 0.0;
         u64 key = kNoKey;
-        for (int rb = row_lo; rb < row_hi; rb += kLdsRows) {
+        // scan cursor: where the rows x columns scan below starts (the probe moves it on when it finds nothing)
+        int si = ci, sj = cj;
+        bool probe_hit = false;
+        long long probe_adj = 0;
+        int4 win = make_int4(0, 0, 0, 0);   // probe hit: positions of the pair's nodes and their successors
+        if constexpr (MODE == TSP_2OPT_FIRST) {
+            // ---- probe: the next 512 pairs in scan order, one per thread --------------------------------------
+            // The distance from the cursor to the next improving pair is very skewed: on a random individual of rand5000
+            // (40 519 moves) half of the hits lie within 64 pairs of the cursor and 77 % within 512, while a rows x columns
+            // batch evaluates thousands of pairs before its first vote.  So every step first looks at the 512 pairs
+            // that follow the cursor (heuristics.c:452-454 order; they span at most a few rows), thread t at the t-th:
+            // the hit of the lowest thread is the reference's next move, and the adjacent pairs the reference skips on
+            // its way there (:471) are counted from the same ballots -- no arg-min, no counting pass, no second barrier.
+            // (rows of fewer than 128 columns: 512 pairs could span more than the four row changes below -- no probe there)
+            if (probe && ci <= n - 134) {
+#ifdef TSP_STAMPS
+                const unsigned long long pq0 = clock64();
+                unsigned long long pq1 = pq0;
+#endif
+                int i = ci, j = cj + 1 + tid;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (j >= n) { j = j - n + i + 2; i += 1; }
+                const bool act = j < n && i < n - 1;
+                bool hit = false, adjp = false;
+                double delta = 0.0;
+                int win_a1 = 0, win_b1 = 0;
+                if (act) {
+                    const NodeRec ri = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, i);
+                    const NodeRec rj = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, j);
+                    win_a1 = ri.succ; win_b1 = rj.succ;
+                    adjp = j == ri.succ || rj.succ == i;   // heuristics.c:471
+#ifdef TSP_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    pq1 = clock64();
+#endif
+                    // one pair per lane: a wave takes as long as its slowest lane, so the bound tiers of the rows x columns
+                    // scan would only add their cost to the exact evaluation of the lanes that pass them
+                    if (!adjp) {
+                        delta = pair_delta<WT, INT>(ri, rj);
+                        hit = delta < 0;
+                    }
+                }
+                const unsigned long long hb = __ballot(hit), ab = __ballot(adjp);
+#ifdef TSP_STAMPS
+                const unsigned long long pq2 = clock64();
+#endif
+                const int wv = tid >> 6, ln = tid & 63;
+                if (ln == 0) {
+                    s_k[wv] = hb;
+                    s_ll[wv] = (long long)ab;
+                }
+                if (hb && ln == __builtin_ctzll(hb)) {
+                    s_d[wv] = delta; s_k[8 + wv] = make_key(i, j);
+                    s_win[wv] = make_int4((int)pos[i], (int)pos[j], win_a1, win_b1);   // the move needs no further look at the tour
+                }
+                // the pair of the last thread: where the scan goes on after a probe without a hit
+                int ei = ci, ej = cj + kLdsThreads;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (ej >= n) { ej = ej - n + ei + 2; ei += 1; }
+                __syncthreads();
+#ifdef TSP_STAMPS
+                const unsigned long long pq3 = clock64();
+                if (tour == 0 && tid == 0) { scn[5] += pq1 - pq0; scn[6] += pq2 - pq1; scn[7] += pq3 - pq2; }
+#endif
+                {   // every wave reads the eight wave results once (lane w: wave w) and reduces them in registers
+                    constexpr int NWV = kLdsThreads / 64;
+                    const int lw = ln & (NWV - 1);
+                    const unsigned long long h = s_k[lw], am = (unsigned long long)s_ll[lw];
+                    const double dw = s_d[lw];
+                    const u64 kw = s_k[8 + lw];
+                    const int4 ww = s_win[lw];
+                    const unsigned long long hm = __ballot(ln < NWV && h != 0ull);
+                    probe_hit = hm != 0ull;
+                    const int fw = probe_hit ? __builtin_ctzll(hm) : NWV;   // first wave with a hit
+                    const unsigned hlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)h, fw & (NWV - 1));
+                    const unsigned hhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(h >> 32), fw & (NWV - 1));
+                    const unsigned long long hw = ((unsigned long long)hhi << 32) | hlo;
+                    const int fl = hw ? __builtin_ctzll(hw) : 63;
+                    // adjacent pairs up to the hit (all of them when there is none)
+                    const unsigned long long keep = lw < fw ? ~0ull : (lw == fw ? ((2ull << fl) - 1ull) : 0ull);
+                    int ac = ln < NWV ? __popcll(am & keep) : 0;
+                    ac = wave_sum_to_lane63(ac);
+                    probe_adj = __builtin_amdgcn_readlane(ac, 63);
+                    if (probe_hit) {
+                        bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dw), fw), __builtin_amdgcn_readlane(__double2loint(dw), fw));
+                        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
+                        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(kw >> 32), fw);
+                        key = ((u64)khi << 32) | klo;
+                        win.x = __builtin_amdgcn_readlane(ww.x, fw); win.y = __builtin_amdgcn_readlane(ww.y, fw);
+                        win.z = __builtin_amdgcn_readlane(ww.z, fw); win.w = __builtin_amdgcn_readlane(ww.w, fw);
+                    }
+                }
+                if (!probe_hit) { si = ei; sj = ej; }
+            }
+            row_lo = si; row_hi = min(si + chunk, n - 1);
+#ifdef TSP_STAMPS
+            LDS_T(4);
+            if (probe_hit) prof[5] += 1;
+#endif
+        }
+
+        // ---- scan ------------------------------------------------------------------------------
+        for (int rb = row_lo; rb < row_hi && !probe_hit; rb += kLdsRows) {
             const int nr = min(kLdsRows, row_hi - rb);
             __syncthreads();
             if (tid < nr) s_rows[tid] = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, rb + tid);
@@ -130,7 +236,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             // (512 then 2048 was measured: no better; two batches per vote: 3 % better on configs[3] and [4]).
             constexpr int U = MODE == TSP_2OPT_FIRST ? 2 : 4;   // FIRST: 1024 columns per vote (measured: 1 -> 2: -3 %, 4: +2 %)
             // batches that hold no column above the rows (or, for the cursor's row alone, above the cursor) are skipped
-            const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == ci) ? cj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
+            const int jbase = MODE == TSP_2OPT_FIRST ? ((max(rb, (nr == 1 && rb == si) ? sj : 0) + 1) / kLdsThreads) * kLdsThreads : 0;
             const bool vote = n - jbase > 2 * kLdsThreads;   // a vote is a barrier: not for two batches
             for (int j0 = jbase + tid; j0 - tid < n; j0 += U * kLdsThreads) {
 #ifdef TSP_STAMPS
@@ -173,7 +279,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                         const int i = rb + r;
                         const NodeRec ri = s_rows[r];
                         bool ok = j > i && j != ri.succ && rj.succ != i;  // heuristics.c:471 / tabusearch.c:134
-                        if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > ci || j > cj);
+                        if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > si || j > sj);
                         const u64 kq = make_key(i, j);
                         if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && kq < key;
                         if constexpr (has_root_filter<WT>()) {
@@ -211,7 +317,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             }
         }
         LDS_T(0);
-        block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
+        if (!probe_hit) block_argmin<MODE == TSP_2OPT_BEST>(bd, key, s_d, s_k);
         LDS_T(1);
         const bool found = key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0);
         const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
@@ -221,7 +327,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         int ni = wi, nj = wj;
         if constexpr (MODE == TSP_2OPT_FIRST) {
             if (!found) { ni = row_hi - 1; nj = n - 1; }
-            if (count_evals) {
+            if (probe_hit) adj = probe_adj;   // counted by the probe's ballots
+            else if (count_evals) {
                 const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
                 long long c = 0;
                 for (int r = ci + tid; r <= ni; r += kLdsThreads) {
@@ -231,7 +338,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     c += (s > r && ks > lo && ks <= hi) ? 1 : 0;
                     c += (q > r && kq > lo && kq <= hi) ? 1 : 0;
                 }
-                adj = block_sum<long long>(c, s_ll);
+                adj_acc += c;   // summed over the workgroup once, at the end of the launch
             }
         }
 
@@ -239,8 +346,21 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         // ---- move: reverse positions pa+1 .. pb (cyclic) --------------------------------------------
         int L = 0;
         if (found) {
-            const int pa = pos[wi], pb = pos[wj];
-            __syncthreads();  // everyone has read pa/pb (and finished the adjacency reads)
+            // a probe hit carries the positions and successors along: nobody reads the tour between its vote and the swaps,
+            // so the barrier that otherwise separates those reads from the swaps is not needed
+            const int pa = probe_hit ? win.x : (int)pos[wi], pb = probe_hit ? win.y : (int)pos[wj];
+            float new_edge = 0.f;
+            if constexpr (CACHE) {
+                // the two new edges (a, b) and (succ a, succ b) will leave positions pa and pb, which the reversal of the
+                // inner edge lengths does not touch: two threads price them on the old tour, beside the swaps
+                if (tid < 2) {
+                    const int u = tid == 0 ? wi : (probe_hit ? win.z : (int)order[pa + 1 == n ? 0 : pa + 1]);
+                    const int v = tid == 0 ? wj : (probe_hit ? win.w : (int)order[pb + 1 == n ? 0 : pb + 1]);
+                    const double2 c = coord[u], cs = coord[v];
+                    new_edge = (float)dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
+                }
+            }
+            if (!probe_hit) __syncthreads();  // everyone has read pa/pb (and finished the adjacency reads)
             L = pb - pa; if (L < 0) L += n;
             const int half = L >> 1;
             for (int t = tid; t < half; t += kLdsThreads) {
@@ -260,12 +380,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     const float u = dsp[p], w = dsp[q];
                     dsp[p] = w; dsp[q] = u;
                 }
-                __syncthreads();   // order[] holds the new tour
-                if (tid < 2) {
-                    const int p = tid == 0 ? pa : pb;
-                    const double2 c = coord[order[p]], cs = coord[order[p + 1 == n ? 0 : p + 1]];
-                    dsp[p] = (float)dist_xy<WT, INT>(c.x, c.y, cs.x, cs.y);
-                }
+                if (tid < 2) dsp[tid == 0 ? pa : pb] = new_edge;
             }
         }
         __syncthreads();
@@ -298,9 +413,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 }
             }
         } else {
-            const long long r_old = pair_rank(ci, cj, n);
-            scanned += pair_rank(row_hi - 1, n - 1, n) - r_old;
-            evals += pair_rank(ni, nj, n) - r_old - adj;
+            const long long r_new = pair_rank(ni, nj, n);
+            scanned += probe_hit ? kLdsThreads : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
+            evals += r_new - r_cur - adj;
+            r_cur = r_new;
             if (found) {
                 obj += bd;                              // heuristics.c:486
                 moves += 1; reversed += L - 1;
@@ -310,17 +426,18 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 if (row_hi >= n - 1) {                  // sweep complete
                     sweeps += 1;
                     if (obj >= seen) done = 1;          // heuristics.c:492
-                    else { seen = obj; ci = 0; cj = 0; }
+                    else { seen = obj; ci = 0; cj = 0; r_cur = 0; }
                 } else { ci = row_hi - 1; cj = n - 1; }
             }
         }
     }
 
 #ifdef TSP_STAMPS
-    if (tour == 0 && tid == 0) { for (int k = 0; k < 4; ++k) g_lds_prof[k] += prof[k]; g_lds_prof[7] += steps - st->steps; for (int k = 0; k < 5; ++k) g_lds_scan[k] += scn[k]; }
+    if (tour == 0 && tid == 0) { for (int k = 0; k < 7; ++k) g_lds_prof[k] += prof[k]; g_lds_prof[7] += steps - st->steps; for (int k = 0; k < 8; ++k) g_lds_scan[k] += scn[k]; }
 #endif
     // ---- write back ---------------------------------------------------------------------------------------
     __syncthreads();
+    if constexpr (MODE == TSP_2OPT_FIRST) evals -= block_sum<long long>(adj_acc, s_ll);
     for (int v = tid; v < n; v += kLdsThreads) order_g[v] = (int)order[v];
     if (tid == 0) {
         st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
@@ -352,7 +469,7 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin);
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 1));
     return hipGetLastError();
 }
 
