@@ -67,6 +67,7 @@ struct ClusterArgs {
     unsigned long long *slots;   // B x 2 x C x kClSlotGranules
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
+    int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up
     int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
@@ -380,12 +381,76 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 #ifdef TSP_STAMPS
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #endif
+    unsigned xep = 0;        // exchanges so far (their epoch: a step decided by the probe has none)
+    bool probe_on = true;    // FIRST: the last hit lay close to the cursor (every workgroup keeps the same value)
     for (int iter = 0; iter < a.max_iters && !done; ++iter) {
         int row_lo = 0, row_hi = n - 1;
-        if constexpr (!BEST) { row_lo = ci; row_hi = min(ci + chunk, n - 1); }
         double bd = 0.0;
         u64 key = kNoKey;
         unsigned ipair = 0;
+        int si = ci, sj = cj;    // FIRST: where the tiles scan starts (the probe moves it on when it finds nothing)
+        bool probe_hit = false;
+        long long probe_adj = 0;
+        if constexpr (!BEST) {
+            // ---- probe: the next 512 pairs in scan order, one per thread (see two_opt_lds.hip) -----------------
+            // Every workgroup of the cluster runs it on its own replica and gets the same answer: a step the probe
+            // decides needs no exchange at all.  It only runs while hits come close together (the distance of the
+            // last one, the same number in every workgroup): a sparse descent would pay for it at every step.
+            if (a.probe > 0 && probe_on && ci <= n - 134) {
+                int i = ci, j = cj + 1 + tid;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (j >= n) { j = j - n + i + 2; i += 1; }
+                const bool act = j < n && i < n - 1;
+                bool hit = false, adjp = false;
+                double delta = 0.0;
+                if (act) {
+                    const NodeRec ri = cl_node<WT, INT, CT>(coord, order, pos, n, i);
+                    const NodeRec rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
+                    adjp = j == ri.succ || rj.succ == i;   // heuristics.c:471
+                    if (!adjp) {
+                        delta = pair_delta<WT, INT>(ri, rj);
+                        hit = delta < 0;
+                    }
+                }
+                w_lane += __popcll(__ballot(act));
+                w_ex += __popcll(__ballot(act && !adjp));
+                const unsigned long long hb = __ballot(hit), ab = __ballot(adjp);
+                if (lane == 0) { s_k[wave] = hb; s_ll[wave] = (long long)ab; }
+                if (hb && lane == __builtin_ctzll(hb)) { s_d[wave] = delta; s_k[8 + wave] = make_key(i, j); }
+                int ei = ci, ej = cj + kClThreads;   // the last thread's pair: where the scan goes on after a probe without a hit
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (ej >= n) { ej = ej - n + ei + 2; ei += 1; }
+                __syncthreads();
+                {   // every wave reads the eight wave results once (lane w: wave w) and reduces them in registers
+                    const int lw = lane & (kClWaves - 1);
+                    const unsigned long long h = s_k[lw], am = (unsigned long long)s_ll[lw];
+                    const double dw = s_d[lw];
+                    const u64 kw = s_k[8 + lw];
+                    const unsigned long long hm = __ballot(lane < kClWaves && h != 0ull);
+                    probe_hit = hm != 0ull;
+                    const int fw = probe_hit ? __builtin_ctzll(hm) : kClWaves;   // first wave with a hit
+                    const unsigned hlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)h, fw & (kClWaves - 1));
+                    const unsigned hhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(h >> 32), fw & (kClWaves - 1));
+                    const unsigned long long hw = ((unsigned long long)hhi << 32) | hlo;
+                    const int fl = hw ? __builtin_ctzll(hw) : 63;
+                    const unsigned long long keep = lw < fw ? ~0ull : (lw == fw ? ((2ull << fl) - 1ull) : 0ull);
+                    int ac = lane < kClWaves ? __popcll(am & keep) : 0;
+                    ac = wave_sum_to_lane63(ac);
+                    probe_adj = __builtin_amdgcn_readlane(ac, 63);
+                    if (probe_hit) {
+                        bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dw), fw), __builtin_amdgcn_readlane(__double2loint(dw), fw));
+                        const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
+                        const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(kw >> 32), fw);
+                        key = ((u64)khi << 32) | klo;
+                        ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
+                    }
+                }
+                if (!probe_hit) { si = ei; sj = ej; __syncthreads(); }   // the vote's scratch is rewritten by the arg-min below
+            }
+            row_lo = si; row_hi = min(si + chunk, n - 1);
+        }
 
         if constexpr (SORTED) {
             // ---- sorted scan: box tests on this workgroup's share of the group pairs, then the survivors ------
@@ -586,14 +651,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             const int nrb = cl_div(nrows + rpt - 1, rpt);
             int hit_rb = nrb;   // FIRST: first row block in which this workgroup has found an improving pair
             bool any_hit = false;
-            for (int t = c; t < nrb * nb; t += C) {
+            for (int t = c; t < nrb * nb && !probe_hit; t += C) {
                 const int rbi = cl_div(t, nb), b = t - rbi * nb;
                 if (!BEST && rbi > hit_rb) break;   // later rows only hold later pairs
                 const int rb = row_lo + rbi * rpt;
                 const int nr = min(rpt, row_hi - rb);
                 const int j = b * kClThreads + tid;
                 // no column of this batch above the first row (or, in the cursor's row alone, above the cursor)
-                const int jmin = (!BEST && nr == 1 && rb == ci) ? max(rb, cj) : rb;
+                const int jmin = (!BEST && nr == 1 && rb == si) ? max(rb, sj) : rb;
                 if (b * kClThreads + kClThreads - 1 <= jmin) continue;
                 CL_T(8);
                 __syncthreads();
@@ -612,7 +677,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         const int i = rb + r;
                         const NodeRec ri = s_rows[r];
                         bool ok = act && j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
-                        if constexpr (!BEST) ok = ok && (i > ci || j > cj);
+                        if constexpr (!BEST) ok = ok && (i > si || j > sj);
                         const u64 kq = make_key(i, j);
                         if constexpr (!BEST) ok = ok && kq < key;
                         if constexpr (has_root_filter<WT>()) {
@@ -647,7 +712,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
         // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
         // winners through LDS to the first wave, which reduces them, runs the exchange and hands the result back
-        {
+        if (!probe_hit) {
             if constexpr (!SORTED) { if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key); }
             const u64 mykey = key;
             wave_argmin<BEST>(bd, key);
@@ -655,9 +720,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) ipair = (unsigned)__builtin_amdgcn_readlane((int)ipair, __builtin_ctzll(owners));
             if (lane == 0) { s_d[wave] = bd; s_k[wave] = key; s_ip[wave] = ipair; }
         }
-        __syncthreads();
+        if (!probe_hit) __syncthreads();
         CL_T(2);
-        if (wave == 0) {
+        if (wave == 0 && !probe_hit) {
             double d = 0.0;
             u64 k2 = kNoKey;
             unsigned ip = 0;
@@ -669,12 +734,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
-            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, (unsigned)(iter + 1), cd, a.err, a.spin_limit);
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
         }
-        __syncthreads();
-        if (*s_fail) { failed = true; break; }
-        bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        if (!probe_hit) {
+            __syncthreads();
+            if (*s_fail) { failed = true; break; }
+            bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        }
         CL_T(3);
         const bool found = key != kNoKey && (!BEST || bd < 0);
         const int wi = found ? (int)(ipair >> 16) : -1, wj = found ? (int)(ipair & 0xffffu) : -1;   // internal ids
@@ -684,7 +751,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         int ni = wi, nj = wj;
         if constexpr (!BEST) {
             if (!found) { ni = row_hi - 1; nj = n - 1; }
-            if (a.count_evals && c == 0) {
+            if (probe_hit) adj = probe_adj;   // counted by the probe's ballots
+            else if (a.count_evals && c == 0) {
                 const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
                 long long cnt = 0;
                 for (int r = ci + tid; r <= ni; r += kClThreads) {
@@ -765,9 +833,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 }
             }
         } else {
-            const long long r_old = pair_rank(ci, cj, n);
-            scanned += pair_rank(row_hi - 1, n - 1, n) - r_old;
-            evals += pair_rank(ni, nj, n) - r_old - adj;
+            const long long r_old = pair_rank(ci, cj, n), r_new = pair_rank(ni, nj, n);
+            scanned += probe_hit ? kClThreads : pair_rank(row_hi - 1, n - 1, n) - r_old;
+            evals += r_new - r_old - adj;
+            if (found) probe_on = r_new - r_old <= a.probe;
             if (found) {
                 obj += bd;                              // heuristics.c:486
                 moves += 1; reversed += Lr - 1;
@@ -994,6 +1063,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
     a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;
+    a.probe = env_int("TSP_CLUSTER_PROBE", 4096);
     a.dbg = env_int("TSP_CLUSTER_DEBUG", 0);
     a.stage_pairs = p.stage_pairs;
     a.spin_limit = (unsigned)std::max(16, env_int("TSP_CLUSTER_SPIN_LIMIT", (int)kClSpinLimit));

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     double obj = st->obj, seen = st->seen_cost;
     long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
               scanned = st->pairs_scanned, steps = st->steps;
+    bool probe_on = true;                       // FIRST: the last hit lay within `probe` pairs of the cursor
     long long adj_acc = 0;                      // this thread's share of the adjacent pairs the reference skipped (heuristics.c:471)
     long long r_cur = pair_rank(ci, cj, n);     // rank of the cursor in scan order
     __syncthreads();
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             // the hit of the lowest thread is the reference's next move, and the adjacent pairs the reference skips on
             // its way there (:471) are counted from the same ballots -- no arg-min, no counting pass, no second barrier.
             // (rows of fewer than 128 columns: 512 pairs could span more than the four row changes below -- no probe there)
-            if (probe && ci <= n - 134) {
+            if (probe > 0 && probe_on && ci <= n - 134) {
 #ifdef TSP_STAMPS
                 const unsigned long long pq0 = clock64();
                 unsigned long long pq1 = pq0;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             const long long r_new = pair_rank(ni, nj, n);
             scanned += probe_hit ? kLdsThreads : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
             evals += r_new - r_cur - adj;
+            if (found) probe_on = r_new - r_cur <= probe;
             r_cur = r_new;
             if (found) {
                 obj += bd;                              // heuristics.c:486
@@ -469,7 +471,7 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 1));
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 65536));
     return hipGetLastError();
 }
 
