@@ -202,6 +202,13 @@ int tsp_dev_tours_two_opt_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, i
  * node or one of (a,a1) (b,b1) (a,b) (a1,b1) is in the tabu list (check_tenure with its lazy clears, in that order); else
  * the 2-exchange is carried out and (a,a1), (b,b1) are stamped with iter.  *accepted = 1 / 0. */
 int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted);
+/* One iteration of tabu() (src/tabusearch.c:238-309) in two waits for the device: alg_2opt_tabu on resident tour 0; if its
+ * cost is below *best_obj the tour becomes the incumbent (as tsp_dev_tours_snapshot; *best_obj updated, *improved = 1,
+ * :241-249); then ONE trial of the kick with the host-drawn a, b (as tsp_dev_tours_tabu_kick; *accepted) -- further
+ * trials, if that one is rejected, go through tsp_dev_tours_tabu_kick.  Returns the run's status; with a time limit hit
+ * no kick is made (:255-258).  obj / improved / accepted may be NULL. */
+int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
+                                 double *best_obj, double *obj, int *improved, int *accepted);
 /* kick() of src/vns.c:11-100 with the three host-drawn, sorted tour positions p1 < p2 < p3 (positions of the walk from
  * node 0): segments tour[p1+1..p2] and tour[p2+1..p3] swap places; the recomputed cost (:77-86) goes to the control block
  * and to *obj (may be NULL). */

@@ -156,6 +156,8 @@ int tsp_grid_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int i
 int tsp_grid_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj);
 int tsp_grid_snapshot(tsp_dev_tours *t, bool restore);
 int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj);
+int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
+                            double *best_obj, double *obj, int *improved, int *accepted);
 
 extern "C" {
 
@@ -521,6 +523,13 @@ int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, 
     if (!t) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
     return tsp_grid_tabu_kick(t, tabu, a, b, iter, tenure, accepted);
+}
+
+int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
+                                 double *best_obj, double *obj, int *improved, int *accepted) {
+    if (!t) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_tabu_iteration(t, tabu, iter, tenure, time_limit_s, a, b, best_obj, obj, improved, accepted);
 }
 
 int tsp_dev_tours_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj) {

@@ -405,7 +405,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     if (sorted_run(t, mode, tabu) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
         launch_flush(t);
         TSP_HIP_TRY(hipGetLastError());
-        if (sync) TSP_HIP_TRY(hipStreamSynchronize(s));
+        if (sync == 1) TSP_HIP_TRY(hipStreamSynchronize(s));   // sync == 2: the caller queues more work and waits once
     }
     if ((status == TSP_TIME_LIMIT_EXCEEDED || (sync && !finished)) && mode == TSP_2OPT_BEST) {
         // the reference recomputes the cost on every exit path (tabusearch.c:168-172); a run capped by max_steps too
@@ -505,6 +505,58 @@ int tsp_grid_snapshot(tsp_dev_tours *t, bool restore) {
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
     return TSP_OK;
+}
+
+// One iteration of tabu() (src/tabusearch.c:238-309) with two waits for the device instead of five: alg_2opt_tabu on the
+// resident tour; the poll that finds it finished also brings its cost (:168-172), so the host decides about the incumbent
+// (:241-249) and queues, behind the run's last launches, the device-to-device snapshot and the first trial of the kick with
+// the nodes a, b it has drawn (:264-265; nothing else draws in between), and waits once for all of it.
+int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
+                            double *best_obj, double *obj, int *improved, int *accepted) {
+    if (!t || !tabu || t->B != 1 || tabu->inst != t->inst || !best_obj || a < 0 || b < 0 || a >= t->n || b >= t->n) return TSP_DEV_E_ARG;
+    int rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
+    if (!rc) rc = kick_buffers(t);
+    if (rc) return rc;
+    int done = 0;
+    const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 2, &done);
+    if (status < 0) return status;
+    hipStream_t s = t->inst->ctx->stream;
+    if (improved) *improved = 0;
+    if (accepted) *accepted = 0;
+    if (status != TSP_OK || !done) {   // time limit: the cost was recomputed by the run; no kick (tabusearch.c:255-258)
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        const double c = t->h_state[0].obj;
+        if (obj) *obj = c;
+        if (c < *best_obj) {   // the incumbent is updated before the status is looked at (:241-249, :255)
+            *best_obj = c;
+            if (improved) *improved = 1;
+            const int rc2 = tsp_grid_snapshot(t, false);
+            if (rc2) return rc2;
+        }
+        return status;
+    }
+    const double cost = t->h_state[0].obj;   // the poll that saw `done` carried the recomputed cost
+    if (obj) *obj = cost;
+    if (cost < *best_obj) {
+        *best_obj = cost;
+        if (improved) *improved = 1;
+        const size_t bn = (size_t)t->n;
+        if (!t->d_order_snap) TSP_HIP_TRY(hipMalloc(&t->d_order_snap, bn * sizeof(int)));
+        TSP_HIP_TRY(hipMemcpyAsync(t->d_order_snap, t->d_order, bn * sizeof(int), hipMemcpyDeviceToDevice, s));
+        t->h_obj_snap.assign(1, cost);
+    }
+    hipLaunchKernelGGL(k_tabu_kick, dim3(1), dim3(kApplyThreads), 0, s, t->d_order, t->d_pos, tabu->d_stamp, t->n, a, b, iter,
+                       tenure, t->d_kick_result, tabu->list_valid ? tabu->d_list : nullptr, tabu->d_list_n, tabu->list_cap);
+    TSP_HIP_TRY(hipMemcpyAsync(t->h_kick_result, t->d_kick_result, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    TSP_HIP_TRY(hipGetLastError());
+    if (t->h_kick_result[0] && tabu->list_valid) {
+        tabu->list_ub += 2;
+        if (tabu->list_ub > tabu->list_cap) tabu->list_valid = false;
+    }
+    if (accepted) *accepted = t->h_kick_result[0];
+    return status;
 }
 
 // alg_2opt_tabu on the resident tour 0 (no upload, no download): *obj = the recomputed cost (tabusearch.c:168-172)

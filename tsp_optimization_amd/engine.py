@@ -81,6 +81,7 @@ def lib():
         L.tsp_dev_tours_two_opt.argtypes = [vp, C.c_int, C.c_int, C.c_double, dp]
         L.tsp_dev_tours_two_opt_tabu.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, dp]
         L.tsp_dev_tours_tabu_kick.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ip]
+        L.tsp_dev_tours_tabu_iteration.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
         L.tsp_dev_tours_vns_kick.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
         L.tsp_dev_tours_snapshot.argtypes = [vp]
         L.tsp_dev_tours_restore.argtypes = [vp]
@@ -98,7 +99,7 @@ EXPORTED = [
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
-    "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_vns_kick",
+    "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
 ]
 
@@ -350,6 +351,14 @@ class Tours:
         acc = C.c_int(0)
         _check(lib().tsp_dev_tours_tabu_kick(self._h, tabu._h, a, b, iter_, tenure, C.byref(acc)))
         return bool(acc.value)
+
+    def tabu_iteration(self, tabu, iter_, tenure, a, b, best_obj, time_limit=-1.0):
+        """-> (status, obj, best_obj', improved, accepted): alg_2opt_tabu, incumbent, first kick trial (tabusearch.c:238-309)"""
+        best, obj, imp, acc = C.c_double(best_obj), C.c_double(0), C.c_int(0), C.c_int(0)
+        rc = lib().tsp_dev_tours_tabu_iteration(self._h, tabu._h, iter_, tenure, time_limit, a, b, C.byref(best), C.byref(obj),
+                                                C.byref(imp), C.byref(acc))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        return rc, obj.value, best.value, bool(imp.value), bool(acc.value)
 
     def vns_kick(self, p1, p2, p3):
         obj = C.c_double(0)

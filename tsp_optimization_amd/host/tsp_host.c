@@ -498,20 +498,22 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         gettimeofday(&t1, 0);
         if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
         double obj = 0.0;
+        int accepted = 0, improved = 0;
+        /* the first draws of the kick (:264-265) are made before the call: nothing else draws until then, and the call
+         * carries them to the device behind the run's last launches (one wait less per iteration) */
+        int a = rand_choice(0, n), b = rand_choice(0, n);
         pthread_mutex_lock(&g_lock);
-        rc = tsp_dev_tours_two_opt_tabu(t, tb, iter, tenure, limit_of(inst), &obj);   /* :238 */
-        if (rc >= 0 && obj < best_obj) { best_obj = obj; have_best = 1; int rc2 = tsp_dev_tours_snapshot(t); if (rc2) rc = rc2; }   /* :241-249 */
+        rc = tsp_dev_tours_tabu_iteration(t, tb, iter, tenure, limit_of(inst), a, b, &best_obj, &obj, &improved, &accepted);   /* :238-249 */
         pthread_mutex_unlock(&g_lock);
-        if (rc < 0) dev_fail("tsp_dev_tours_two_opt_tabu", rc);
+        if (improved) have_best = 1;
+        if (rc < 0) dev_fail("tsp_dev_tours_tabu_iteration", rc);
         if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
-        for (;;) {                                           /* :262-287: draws until a pair of free, disjoint edges comes up */
-            const int a = rand_choice(0, n), b = rand_choice(0, n);
-            int accepted = 0;
+        while (!accepted) {                                  /* :262-287: draws until a pair of free, disjoint edges comes up */
+            a = rand_choice(0, n); b = rand_choice(0, n);
             pthread_mutex_lock(&g_lock);
             rc = tsp_dev_tours_tabu_kick(t, tb, a, b, iter, tenure, &accepted);   /* + :288-290 move, :306-309 stamps */
             pthread_mutex_unlock(&g_lock);
             if (rc) dev_fail("tsp_dev_tours_tabu_kick", rc);
-            if (accepted) break;
         }
         if (policy == 0) {                                   /* step_policy :33-37 */
             if (iter % 100 == 0) tenure = (tenure == lo) ? hi : lo;
