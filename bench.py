@@ -403,8 +403,42 @@ def main():
                     "achieved": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9,
                     "frac": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
+    def tabu_section():
+        # alg_2opt_tabu WITH a tabu list (tabusearch.c:127-165): the reference reads four stamps of the n(n-1)/2-int list
+        # per pair -- 16 B x 49 985 000 = 800 MB per sweep, the one sweep of the path that is HBM-bound when executed
+        # as written (k_step<TABU>, TSP_TABU_DENSE=1).  The default works from the compact list of non-zero stamps
+        # (two_opt_tabu_list.hpp) and gives the same tours, counters and stamp array.
+        live = 400                                     # what tabu() holds at tenure 200 (2 stamps per iteration)
+        rng = np.random.default_rng(7)
+        idx = rng.choice(N_NODES * (N_NODES - 1) // 2, size=live, replace=False).astype(np.int32)
+        res = {}
+        ref = None
+        for label, dense in (("from_the_list_of_nonzero_stamps", "0"), ("four_stamp_reads_per_pair", "1")):
+            os.environ["TSP_TABU_DENSE"] = dense
+            tb = E.Tabu(inst)
+            tb.set(idx, np.full(live, 5, dtype=np.int32))
+            tt = E.Tours(inst, 1)
+            tt.upload(succ0[0], obj0[0])
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            rc, o = tt.two_opt_tabu(tb, 6, 200)
+            dt = time.perf_counter() - t1
+            s_t, _, st_t = tt.download()
+            key = (fnv1a(s_t[0]), o, st_t[0]["sweeps"], st_t[0]["evals"], st_t[0]["moves"])
+            ref = ref or key
+            res[label] = {"descent_s": dt, "sweeps": st_t[0]["sweeps"], "us_per_sweep": 1e6 * dt / max(1, st_t[0]["sweeps"]),
+                          "reference_evals": st_t[0]["evals"], "final_cost": o, "same_result_as_the_other_path": bool(key == ref),
+                          "stamp_bytes_the_reference_reads_per_sweep": 16 * pairs_per_sweep,
+                          "those_bytes_per_s_GBps": 16.0 * pairs_per_sweep * st_t[0]["sweeps"] / dt / 1e9}
+            tb.close(); tt.close()
+        os.environ.pop("TSP_TABU_DENSE", None)
+        res["four_stamp_reads_per_pair"]["hbm_frac"] = res["four_stamp_reads_per_pair"]["those_bytes_per_s_GBps"] / HBM_PEAK_GBS
+        res["live_stamps"] = live
+        out["alg_2opt_tabu_with_a_list"] = res
+
     if rank == 0 and world == 1 and not args.no_extras:
         guarded("time_to_local_optimum", extras_section)
+        guarded("alg_2opt_tabu_with_a_list", tabu_section)
 
     if not args.no_extras:
         out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device)
