@@ -54,6 +54,27 @@ for c in range(cases):
     rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
     ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
     del os.environ["TSP_CLUSTER_BLOCKS"]
+    if n <= 8000:   # the LDS engine (one workgroup per tour), first improvement, with and without the probe
+        os.environ["TSP_LDS_PROBE"] = str(int(rng.choice([0, 1, 600, 1 << 30])))
+        rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=2)
+        del os.environ["TSP_LDS_PROBE"]
+        ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+    if 8 <= n <= 220 and wt in (O.EUC_2D, O.ATT, O.CEIL_2D):
+        # alg_2opt_tabu with a dense random tabu list (live and expired stamps, tour edges included): the list path
+        it, ten = int(rng.integers(2, 40)), int(rng.integers(0, 15))
+        stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
+        for _ in range(int(rng.choice([1, n // 2, 2 * n]))):
+            a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+            if rng.random() < 0.4: b = int(tour[a])
+            if a != b: stamps[min(a, b) * n + max(a, b) - (min(a, b) + 1) * (min(a, b) + 2) // 2] = int(rng.integers(1, it + 1))
+        exp = stamps.copy()
+        _, ts, to, tst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic, tabu=exp, iter_=it, tenure=ten)
+        tb = E.Tabu(inst)
+        tb.upload(stamps)
+        rc, s, o, st, _ = tb.two_opt(tour, it, ten)
+        ok = ok and (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"])
+        ok = ok and (tb.download() == exp).all() and tb.list_info()[1]
+        tb.close()
     if c % 3 == 0 and n >= 8:
         # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
         t3 = np.stack([random_tour(n, rng) for _ in range(3)])
