@@ -165,8 +165,10 @@ def test_cluster_gives_up_and_the_descent_is_redone_on_the_grid_engine(eng, ctx,
 
 
 # ---- drivers on resident tours: the kicks of tabu() and HEU_VNS on the device --------------------------------------
-def test_resident_tabu_iterations_equal_oracle(eng, ctx):
-    """tabusearch.c:238-309 through the resident-tour API: alg_2opt_tabu on the device-resident tour with device-resident
+@pytest.mark.parametrize("fused", [False, True])
+def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused):
+    """fused: tsp_dev_tours_tabu_iteration (run + incumbent + first kick trial in one call) instead of the separate calls.
+    tabusearch.c:238-309 through the resident-tour API: alg_2opt_tabu on the device-resident tour with device-resident
     stamps, then the kick as one launch per trial (host-drawn a, b; check_tenure with its lazy clears; 2-exchange; stamps).
     After 60 iterations the tour, its cost and the whole stamp array equal a host replay with the oracle's alg_2opt_tabu."""
     xy, wt = load_instance("pr299")
@@ -195,14 +197,28 @@ def test_resident_tabu_iterations_equal_oracle(eng, ctx):
             return False
         return True
 
+    best = float("inf")
     for it in range(1, 61):
-        rc, obj = tours.two_opt_tabu(tabu, it, tenure)
+        first_trial = None
+        if fused:
+            a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+            rc, obj, nbest, improved, acc0 = tours.tabu_iteration(tabu, it, tenure, a, b, best)
+            assert improved == (obj < best) and nbest == min(best, obj)
+            best = nbest
+            first_trial = (a, b, acc0)
+        else:
+            rc, obj = tours.two_opt_tabu(tabu, it, tenure)
         _, succ, eo, _, _, prev = O.two_opt_best(xy, wt, succ, tabu=stamps, iter_=it, tenure=tenure, want_prev=True)
         assert rc == 0 and obj == eo, it
         while True:
-            a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
-            a1, b1 = int(succ[a]), int(succ[b])
-            acc = tours.tabu_kick(tabu, a, b, it, tenure)
+            if first_trial is not None:
+                a, b, acc = first_trial
+                first_trial = None
+                a1, b1 = int(succ[a]), int(succ[b])
+            else:
+                a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+                a1, b1 = int(succ[a]), int(succ[b])
+                acc = tours.tabu_kick(tabu, a, b, it, tenure)
             if a == b or a1 == b or b1 == a:
                 assert not acc
                 continue

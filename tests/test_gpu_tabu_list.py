@@ -77,8 +77,16 @@ def run_both(eng, inst, tb, xy, wt, succ0, stamps, it, tenure, integer_cost=1):
     return es, exp_st
 
 
+@pytest.fixture(params=["cluster", "grid"])
+def list_engine(request, monkeypatch):
+    """Both engines work from the list: CLUSTER (default when the tour fits its sorted scan) and GRID (TSP_ENGINE=1)."""
+    if request.param == "grid":
+        monkeypatch.setenv("TSP_ENGINE", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_dense_nasty_lists_small(eng, ctx, monkeypatch, seed):
+def test_dense_nasty_lists_small(eng, ctx, monkeypatch, list_engine, seed):
     monkeypatch.setenv("TSP_SORTED_MIN_N", "0")
     rng = np.random.default_rng(1000 + seed)
     n = int(rng.integers(8, 200))
@@ -102,7 +110,7 @@ def test_dense_nasty_lists_small(eng, ctx, monkeypatch, seed):
 
 
 @pytest.mark.parametrize("name,ic", [("pr299", 1), ("att532", 1), ("d493", 0), ("kroA100", 0), ("rand1000", 1)])
-def test_lists_on_instances(eng, ctx, monkeypatch, name, ic):
+def test_lists_on_instances(eng, ctx, monkeypatch, list_engine, name, ic):
     monkeypatch.setenv("TSP_SORTED_MIN_N", "0")
     xy, wt = load_instance(name)
     n = len(xy)
@@ -147,8 +155,9 @@ def test_full_size_list_path_equals_per_pair_path(eng, ctx, monkeypatch):
     # start near the local optimum (the per-pair path needs 0.7 ms per sweep): the full descent first, without a list
     rc, s_opt, o_opt, _ = inst.two_opt(succ0[0], obj0[0], mode=eng.BEST)
     results = []
-    for dense in ("0", "1"):
+    for dense, engine in (("0", "0"), ("1", "0"), ("0", "1")):   # CLUSTER from the list, GRID per pair, GRID from the list
         monkeypatch.setenv("TSP_TABU_DENSE", dense)
+        monkeypatch.setenv("TSP_ENGINE", engine)
         tours = eng.Tours(inst, 1)
         tours.upload(s_opt, o_opt)
         tb = eng.Tabu(inst)
@@ -165,9 +174,10 @@ def test_full_size_list_path_equals_per_pair_path(eng, ctx, monkeypatch):
         s, o, st = tours.download()
         results.append((s[0].copy(), costs, st[0]["evals"], st[0]["sweeps"], st[0]["moves"], tb.download()))
         tb.close(); tours.close()
-    a, b = results
-    assert (a[0] == b[0]).all() and a[1] == b[1]
-    assert a[2:5] == b[2:5]
-    assert (a[5] == b[5]).all()
+    a = results[0]
+    for b in results[1:]:
+        assert (a[0] == b[0]).all() and a[1] == b[1]
+        assert a[2:5] == b[2:5]
+        assert (a[5] == b[5]).all()
     assert np.count_nonzero(a[5]) > 0
     inst.close()

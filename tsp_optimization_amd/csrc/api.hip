@@ -17,7 +17,8 @@ bool tsp_lds_fits(const tsp_dev_inst *inst);
 bool tsp_cluster_fits(const tsp_dev_tours *t, int mode);
 bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode);
 int tsp_cluster_size(const tsp_dev_tours *t, int mode);
-int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through);
+int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through,
+                    tsp_dev_tabu *tabu = nullptr, int iter = 0, int tenure = 0);
 
 void *tsp_io_pool(tsp_dev_inst *inst, size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;

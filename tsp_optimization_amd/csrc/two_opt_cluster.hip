@@ -67,6 +67,13 @@ struct ClusterArgs {
     unsigned long long *slots;   // B x 2 x C x kClSlotGranules
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
+    // BEST, sorted scan, with a tabu list (two_opt_tabu_list.hpp has the method): stamps, the compact list of the non-zero
+    // ones, and the handle's side words {skipped pairs of the run, live tour edges of sweep parity 0 / 1}
+    int *tabu;
+    const int2 *tabu_list;
+    const int *tabu_list_n;
+    int tabu_list_cap, iter, tenure;
+    unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     // executed work, per wave (wave-uniform values): rows or row-lanes through tier 0, pairs queued for tier 1, delta
     // expressions, staged records; summed into the tour's control block at the end of the launch
     long long w_lane = 0, w_t1 = 0, w_ex = 0, w_st = 0;
+    long long tabu_cnt = 0;   // this thread's share of the pairs the reference's scan skips as tabu (linear terms)
 #ifdef TSP_STAMPS
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #endif
@@ -560,9 +568,21 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                         if constexpr (INT) { if (a.dbg & 8) { gi = ri.id; gj = rj.id; } else { gi = a.gid[ri.id]; gj = a.gid[rj.id]; } }
                                         const u64 kk = make_key(min(gi, gj), max(gi, gj));
                                         if (delta < bd || kk < key) {
-                                            bd = delta; key = kk;
-                                            ipair = gi < gj ? (((unsigned)ri.id << 16) | (unsigned)rj.id)
-                                                            : (((unsigned)rj.id << 16) | (unsigned)ri.id);
+                                            bool is_tabu = false;
+                                            if (a.tabu) {   // tabusearch.c:137-149 on node ids, a = the lower one, lazy clears included
+                                                const bool lo = gi < gj;
+                                                const int i = lo ? gi : gj, jn = lo ? gj : gi;
+                                                const int a1 = a.gid[lo ? ri.succ : rj.succ], b1 = a.gid[lo ? rj.succ : ri.succ];
+                                                is_tabu = stamp_is_tabu(a.tabu + udir_pos(i, jn, n), a.iter, a.tenure) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(i, a1, n), a.iter, a.tenure) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(jn, b1, n), a.iter, a.tenure) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(i, b1, n), a.iter, a.tenure);
+                                            }
+                                            if (!is_tabu) {
+                                                bd = delta; key = kk;
+                                                ipair = gi < gj ? (((unsigned)ri.id << 16) | (unsigned)rj.id)
+                                                                : (((unsigned)rj.id << 16) | (unsigned)ri.id);
+                                            }
                                         }
                                     }
                                 }
@@ -708,6 +728,58 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
         }
 
+        if constexpr (SORTED) {
+            if (a.tabu) {
+                // ---- side effects of the reference's scan of the tabu list (two_opt_tabu_list.hpp, tabu_side): every
+                // thread of the cluster takes the list entries k = its number, + C x 512, ...; succ / pred come from the
+                // replica (internal ids; the stamps are indexed by node ids)
+                auto nsucc = [&](int v) { int p2 = (int)pos[a.iid[v]] + 1; if (p2 == n) p2 = 0; return a.gid[(int)order[p2]]; };
+                auto npred = [&](int v) { int p2 = (int)pos[a.iid[v]]; p2 = p2 == 0 ? n - 1 : p2 - 1; return a.gid[(int)order[p2]]; };
+                auto live_v = [&](int sv) { return sv != 0 && !(a.iter - sv > a.tenure); };
+                auto live = [&](int x, int y) { return live_v(a.tabu[udir_pos(x, y, n)]); };
+                const int m = min(*a.tabu_list_n, a.tabu_list_cap);
+                for (int k = c * kClThreads + tid; k < m; k += C * kClThreads) {
+                    const int2 e = a.tabu_list[k];
+                    const int u = e.x, v = e.y;
+                    int *sp = a.tabu + udir_pos(u, v, n);
+                    const int sv = *sp;
+                    if (sv == 0) continue;
+                    const int su = nsucc(u), s2 = nsucc(v);
+                    const bool uv = su == v, vu = s2 == u;
+                    if (!live_v(sv)) {
+                        if (!uv && !vu) *sp = 0;
+                        else {
+                            // expired stamp on the tour edge x -> y: cleared iff the reference's chain reaches it
+                            const int x = uv ? u : v, y = uv ? v : u, px = npred(x);
+                            bool looked = false;
+                            for (int b = x + 1; b < n && !looked; ++b) looked = b != y && b != px && !live(x, b);
+                            for (int q = 0; q < x && !looked; ++q) looked = q != px && q != y && !live(q, x) && !live(q, nsucc(q));
+                            if (!looked) looked = y < px && px != nsucc(y) && !live(y, px) && !live(y, nsucc(y)) && !live(px, x);
+                            if (looked) *sp = 0;
+                        }
+                        continue;
+                    }
+                    if (!uv && !vu) {
+                        const int fu = live(u, su) ? 1 : 0, fv = live(v, s2) ? 1 : 0;
+                        tabu_cnt += 1 - fu - fv + fu * fv;
+                    } else {
+                        tabu_cnt += n - 3;
+                        const int y = uv ? v : u, sy = uv ? s2 : su;
+                        if (live(y, sy)) tabu_cnt += 1;
+                        // live tour edges of this sweep, cluster-wide (the C(|F|, 2) term): complete before this workgroup's
+                        // candidate is published, read by the first workgroup after the exchange
+                        atomicAdd(a.tabu_side + 1 + (sweeps & 1), 1ull);
+                        __threadfence();
+                    }
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const int aa = o ? v : u, w = o ? u : v, sa = o ? s2 : su;
+                        const int b = npred(w);
+                        if (b != aa && aa < b && b != sa && !live(aa, b) && !live(aa, sa) && !live(b, w)) tabu_cnt += 1;
+                    }
+                }
+            }
+        }
         CL_T(1);
         // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
         // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
@@ -741,6 +813,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             __syncthreads();
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+        }
+        if constexpr (SORTED) {
+            if (a.tabu && c == 0 && tid == 0) {   // every workgroup's adds of this sweep came before its candidate
+                unsigned long long *fp = a.tabu_side + 1 + (sweeps & 1);
+                const long long f = (long long)atomicAdd(fp, 0ull);
+                if (f) { tabu_cnt -= f * (f - 1) / 2; atomicExch(fp, 0ull); __threadfence(); }   // zero again before this thread publishes the next candidate
+            }
         }
         CL_T(3);
         const bool found = key != kNoKey && (!BEST || bd < 0);
@@ -865,6 +944,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         if (w_t1) __hip_atomic_fetch_add((gll *)&st->tier1_pairs, w_t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w_ex) __hip_atomic_fetch_add((gll *)&st->exact_pairs, w_ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w_st) __hip_atomic_fetch_add((gll *)&st->staged_recs, w_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (SORTED) {
+        if (a.tabu && !failed) {   // uniform: every thread of the workgroup takes part in the sum
+            __syncthreads();
+            const long long tot = block_sum<long long>(tabu_cnt, s_ll);
+            if (tid == 0 && tot) atomicAdd(a.tabu_side, (unsigned long long)tot);
+        }
     }
     // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
     if (failed || c != 0) return;
@@ -996,7 +1082,8 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode) {
 // *fell_through = 1 when the cluster protocol gave up (a workgroup was not resident): the tours in HBM are
 // then exactly as uploaded by the last launch that completed and the caller may continue with another engine.
 // max_steps >= 0 caps the steps per tour (a capped best-improvement run gets its recomputed cost like a timed-out one).
-int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through) {
+int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through,
+                    tsp_dev_tabu *tabu, int iter, int tenure) {
     if (fell_through) *fell_through = 0;
     if (all_done) *all_done = 0;
     if (!t || C < 1 || C > 256) return TSP_DEV_E_ARG;
@@ -1063,6 +1150,12 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
     a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;
+    a.tabu = nullptr; a.tabu_list = nullptr; a.tabu_list_n = nullptr; a.tabu_list_cap = 0; a.iter = iter; a.tenure = tenure; a.tabu_side = nullptr;
+    if (tabu) {   // the caller has brought the handle's list up to date (tsp_tabu_list_prepare) and zeroed the side words
+        if (mode != TSP_2OPT_BEST || !p.sorted || B != 1 || !tabu->list_valid) return TSP_DEV_E_ARG;
+        a.tabu = tabu->d_stamp; a.tabu_list = tabu->d_list; a.tabu_list_n = tabu->d_list_n; a.tabu_list_cap = tabu->list_cap;
+        a.tabu_side = tabu->d_tabu_pairs;
+    }
     a.probe = env_int("TSP_CLUSTER_PROBE", 4096);
     a.dbg = env_int("TSP_CLUSTER_DEBUG", 0);
     a.stage_pairs = p.stage_pairs;

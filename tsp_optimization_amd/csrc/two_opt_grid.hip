@@ -427,6 +427,53 @@ int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
 }
 
 tsp_dev_tours *tsp_scratch_tours(tsp_dev_inst *inst, int B, bool *owned, int *rc);   // api.hip
+// two_opt_cluster.hip
+int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double time_limit_s, int *all_done, int *fell_through,
+                    tsp_dev_tabu *tabu, int iter, int tenure);
+bool tsp_cluster_fits(const tsp_dev_tours *t, int mode);
+bool tsp_cluster_sorted(const tsp_dev_tours *t, int mode);
+int tsp_cluster_size(const tsp_dev_tours *t, int mode);
+
+// alg_2opt_tabu with a list on tour 0 of a handle: the CLUSTER engine when the tour fits its sorted scan and the handle's
+// list of non-zero stamps is usable (one launch per descent, 11 us per sweep at n = 10 000), else the GRID engine (which
+// works from the list as well when it can, and reads four stamps per pair when it cannot).  sync as tsp_grid_run.
+int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int sync, int *all_done) {
+    if (tabu && iter >= 0 && tenure >= 0 && t->B == 1 && env_int("TSP_TABU_DENSE", 0) == 0 && env_int("TSP_ENGINE", 0) != 1 &&
+        tsp_cluster_fits(t, TSP_2OPT_BEST) && tsp_cluster_sorted(t, TSP_2OPT_BEST)) {
+        bool usable = false;
+        int rc = tabu_list_prepare(t, tabu, &usable);
+        if (rc) return rc;
+        if (usable) {
+            hipStream_t s = t->inst->ctx->stream;
+            TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+            int fell = 0;
+            const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, all_done, &fell,
+                                               tabu, iter, tenure);
+            if (!fell) {
+                if (status < 0) return status;
+                tabu->last_run_list = true;
+                hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, s, t->d_state, tabu->d_tabu_pairs);
+                TSP_HIP_TRY(hipGetLastError());
+                if (sync == 1) TSP_HIP_TRY(hipStreamSynchronize(s));
+                return status;
+            }
+            // a workgroup was not resident: the tour in HBM is untouched (stamps it cleared stay cleared: the same
+            // clears are due again), the same descent goes through the GRID engine
+        }
+    }
+    if ((!tabu || iter < 0 || tenure < 0) && t->B == 1 && env_int("TSP_ENGINE", 0) != 1 && tsp_cluster_fits(t, TSP_2OPT_BEST)) {
+        // no list (check_tenure answers 0 before it reads anything, tabusearch.c:84): the plain best-improvement descent
+        hipStream_t s = t->inst->ctx->stream;
+        int fell = 0;
+        const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, all_done, &fell,
+                                           nullptr, 0, 0);
+        if (!fell) {
+            if (status >= 0 && sync == 1) TSP_HIP_TRY(hipStreamSynchronize(s));
+            return status;
+        }
+    }
+    return tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, sync, all_done);
+}
 int tsp_perm_cost_device(tsp_dev_inst *inst, const int *d_perm, long long stride, int B, double *d_out, size_t out_stride_bytes);   // api.hip
 
 // ---- resident-tour drivers (called by the extern "C" wrappers in api.hip) ---------------------------------------
@@ -518,7 +565,7 @@ int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int 
     if (!rc) rc = kick_buffers(t);
     if (rc) return rc;
     int done = 0;
-    const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 2, &done);
+    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 2, &done);
     if (status < 0) return status;
     hipStream_t s = t->inst->ctx->stream;
     if (improved) *improved = 0;
@@ -565,7 +612,7 @@ int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int t
     int rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
     if (rc) return rc;
     int done = 0;
-    const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 1, &done);
+    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 1, &done);
     if (status < 0) return status;
     hipStream_t s = t->inst->ctx->stream;
     TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
@@ -932,7 +979,7 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
     rc = tsp_dev_tours_upload(t, succ, succ_stride, inst->n, obj);
     if (rc) return rc;
     int done = 0;
-    const int status = tsp_grid_run(t, TSP_2OPT_BEST, tabu, iter, tenure, -1, time_limit_s, 1, &done);
+    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 1, &done);
     if (status < 0) return status;
     rc = tsp_dev_tours_download(t, succ, succ_stride, inst->n, obj, stats);
     if (rc) return rc;
