@@ -143,6 +143,7 @@ struct tsp_dev_tours {
     std::vector<double> h_obj_snap;
     int *d_kick_result = nullptr;
     int *h_kick_result = nullptr;    // pinned
+    int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)
     // reset point (device copies of the uploaded tours)
     int *d_order0 = nullptr;

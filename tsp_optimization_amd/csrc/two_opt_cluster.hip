@@ -1191,9 +1191,10 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
         if (e != hipSuccess) { tsp::set_last_error("k_cluster_two_opt launch", e, __FILE__, __LINE__); return TSP_DEV_E_HIP; }
         TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)B, hipMemcpyDeviceToHost, s));
-        int err = 0;
-        TSP_HIP_TRY(hipMemcpyAsync(&err, a.err, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!t->h_cl_err) TSP_HIP_TRY(hipHostMalloc(&t->h_cl_err, sizeof(int)));
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_cl_err, a.err, sizeof(int), hipMemcpyDeviceToHost, s));   // pinned: no staging copy
         TSP_HIP_TRY(hipStreamSynchronize(s));
+        const int err = *t->h_cl_err;
         if (err) {
             tsp::set_last_error("k_cluster_two_opt: a workgroup of the cluster was not resident (exchange gave up)",
                                 hipErrorLaunchFailure, __FILE__, __LINE__);

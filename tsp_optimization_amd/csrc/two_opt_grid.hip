@@ -417,11 +417,15 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
 
 // After another engine has rewritten order[] (two_opt_lds.hip): rebuild pos[], and give BEST runs
 // that were cut short their recomputed cost (tabusearch.c:168-172).
+// Queued, not waited for (everything that follows is ordered behind it on the engine's stream) -- except for the recomputed
+// cost of a run that was cut short, which the caller reads.
 int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
     hipStream_t s = t->inst->ctx->stream;
     hipLaunchKernelGGL(k_build_pos, dim3((t->n + 255) / 256, t->B), dim3(256), 0, s, t->d_order, t->d_pos, t->n);
-    if (timed_out && mode == TSP_2OPT_BEST) launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
+    if (timed_out && mode == TSP_2OPT_BEST) {
+        launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+    }
     TSP_HIP_TRY(hipGetLastError());
     return TSP_OK;
 }
@@ -612,12 +616,14 @@ int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int t
     int rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
     if (rc) return rc;
     int done = 0;
-    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 1, &done);
+    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 2, &done);
     if (status < 0) return status;
-    hipStream_t s = t->inst->ctx->stream;
-    TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
-    if (obj) *obj = t->h_state[0].obj;
+    if (status != TSP_OK || !done) {   // cut short: the recomputed cost was written after the last poll
+        hipStream_t s = t->inst->ctx->stream;
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (obj) *obj = t->h_state[0].obj;   // the poll that saw `done` carried the cost (tabusearch.c:168-172)
     return status;
 }
 
@@ -733,7 +739,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab);
-    (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result);
+    (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result); (void)hipHostFree(t->h_cl_err);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
     delete t;
