@@ -22,16 +22,19 @@ done
 # (4) SQ counters of the cluster kernel
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $O/prof_sq -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-variants > /dev/null 2> $O/pmc_sq.log
 python3 $R/tools/summarize_rocprof.py pmc $O/prof_sq $O/${TAG}_pmc_sq_wave_counters.json > /dev/null
-# (5) alg_2opt_tabu with a list: the per-pair scan (TSP_TABU_DENSE=1, k_step<TABU>) and the list path (k_sweep<TABU>), kernel
-#     times and HBM fetch traffic of both (tools/tabu_time.py: full descents of rand10000 with 0 / 200 / 2000 live stamps)
-for D in 0 1; do
-  export TSP_TABU_DENSE=$D
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tabu$D -- python3 $R/tools/tabu_time.py rand10000 > $O/${TAG}_tabu_time_dense$D.txt 2> $O/trace_tabu$D.log
-  python3 $R/tools/summarize_rocprof.py stats $O/prof_tabu$D $O/${TAG}_kernel_stats_tabu_dense$D.csv > /dev/null
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_tabuf$D -- python3 $R/tools/tabu_time.py rand10000 > /dev/null 2> $O/pmc_tabuf$D.log
-  python3 $R/tools/summarize_rocprof.py pmc $O/prof_tabuf$D $O/${TAG}_pmc_FETCH_SIZE_tabu_dense$D.json > /dev/null
-  rm -rf $O/prof_tabu$D $O/prof_tabuf$D
+# (5) alg_2opt_tabu with a list (tools/tabu_time.py: full descents of rand10000 with 0 / 200 / 2000 live stamps), kernel times
+#     and HBM fetch traffic: cluster = the default (CLUSTER engine from the list of non-zero stamps), grid = TSP_ENGINE=1 (GRID
+#     engine from the list, k_sweep<TABU>), dense = TSP_TABU_DENSE=1 (four stamp reads per pair, k_step<TABU>)
+for V in cluster grid dense; do
+  unset TSP_TABU_DENSE TSP_ENGINE
+  [ $V = grid ] && export TSP_ENGINE=1
+  [ $V = dense ] && export TSP_TABU_DENSE=1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tabu_$V -- python3 $R/tools/tabu_time.py rand10000 > $O/${TAG}_tabu_time_$V.txt 2> $O/trace_tabu_$V.log
+  python3 $R/tools/summarize_rocprof.py stats $O/prof_tabu_$V $O/${TAG}_kernel_stats_tabu_$V.csv > /dev/null
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_tabuf_$V -- python3 $R/tools/tabu_time.py rand10000 > /dev/null 2> $O/pmc_tabuf_$V.log
+  python3 $R/tools/summarize_rocprof.py pmc $O/prof_tabuf_$V $O/${TAG}_pmc_FETCH_SIZE_tabu_$V.json > /dev/null
+  rm -rf $O/prof_tabu_$V $O/prof_tabuf_$V
 done
-unset TSP_TABU_DENSE
+unset TSP_TABU_DENSE TSP_ENGINE
 rm -rf $O/prof_trace $O/prof_trace2 $O/prof_FETCH_SIZE $O/prof_WRITE_SIZE $O/prof_sq
 head -5 $O/${TAG}_kernel_stats.csv; head -6 $O/${TAG}_kernel_stats_exhaustive.csv; tail -2 $O/trace.log

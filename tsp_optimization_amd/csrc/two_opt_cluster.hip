@@ -68,7 +68,7 @@ struct ClusterArgs {
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
     // BEST, sorted scan, with a tabu list (two_opt_tabu_list.hpp has the method): stamps, the compact list of the non-zero
-    // ones, and the handle's side words {skipped pairs of the run, live tour edges of sweep parity 0 / 1}
+    // ones, and the handle's side words {skipped pairs of the run, live tour edges of sweep number mod 3 = 0 / 1 / 2}
     int *tabu;
     const int2 *tabu_list;
     const int *tabu_list_n;
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         double bd = 0.0;
         u64 key = kNoKey;
         unsigned ipair = 0;
+        const int slot_cur = (int)(sweeps % 3), slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
         int si = ci, sj = cj;    // FIRST: where the tiles scan starts (the probe moves it on when it finds nothing)
         bool probe_hit = false;
         long long probe_adj = 0;
@@ -728,58 +729,6 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
         }
 
-        if constexpr (SORTED) {
-            if (a.tabu) {
-                // ---- side effects of the reference's scan of the tabu list (two_opt_tabu_list.hpp, tabu_side): every
-                // thread of the cluster takes the list entries k = its number, + C x 512, ...; succ / pred come from the
-                // replica (internal ids; the stamps are indexed by node ids)
-                auto nsucc = [&](int v) { int p2 = (int)pos[a.iid[v]] + 1; if (p2 == n) p2 = 0; return a.gid[(int)order[p2]]; };
-                auto npred = [&](int v) { int p2 = (int)pos[a.iid[v]]; p2 = p2 == 0 ? n - 1 : p2 - 1; return a.gid[(int)order[p2]]; };
-                auto live_v = [&](int sv) { return sv != 0 && !(a.iter - sv > a.tenure); };
-                auto live = [&](int x, int y) { return live_v(a.tabu[udir_pos(x, y, n)]); };
-                const int m = min(*a.tabu_list_n, a.tabu_list_cap);
-                for (int k = c * kClThreads + tid; k < m; k += C * kClThreads) {
-                    const int2 e = a.tabu_list[k];
-                    const int u = e.x, v = e.y;
-                    int *sp = a.tabu + udir_pos(u, v, n);
-                    const int sv = *sp;
-                    if (sv == 0) continue;
-                    const int su = nsucc(u), s2 = nsucc(v);
-                    const bool uv = su == v, vu = s2 == u;
-                    if (!live_v(sv)) {
-                        if (!uv && !vu) *sp = 0;
-                        else {
-                            // expired stamp on the tour edge x -> y: cleared iff the reference's chain reaches it
-                            const int x = uv ? u : v, y = uv ? v : u, px = npred(x);
-                            bool looked = false;
-                            for (int b = x + 1; b < n && !looked; ++b) looked = b != y && b != px && !live(x, b);
-                            for (int q = 0; q < x && !looked; ++q) looked = q != px && q != y && !live(q, x) && !live(q, nsucc(q));
-                            if (!looked) looked = y < px && px != nsucc(y) && !live(y, px) && !live(y, nsucc(y)) && !live(px, x);
-                            if (looked) *sp = 0;
-                        }
-                        continue;
-                    }
-                    if (!uv && !vu) {
-                        const int fu = live(u, su) ? 1 : 0, fv = live(v, s2) ? 1 : 0;
-                        tabu_cnt += 1 - fu - fv + fu * fv;
-                    } else {
-                        tabu_cnt += n - 3;
-                        const int y = uv ? v : u, sy = uv ? s2 : su;
-                        if (live(y, sy)) tabu_cnt += 1;
-                        // live tour edges of this sweep, cluster-wide (the C(|F|, 2) term): complete before this workgroup's
-                        // candidate is published, read by the first workgroup after the exchange
-                        atomicAdd(a.tabu_side + 1 + (sweeps & 1), 1ull);
-                        __threadfence();
-                    }
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        const int aa = o ? v : u, w = o ? u : v, sa = o ? s2 : su;
-                        const int b = npred(w);
-                        if (b != aa && aa < b && b != sa && !live(aa, b) && !live(aa, sa) && !live(b, w)) tabu_cnt += 1;
-                    }
-                }
-            }
-        }
         CL_T(1);
         // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
         // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
@@ -809,14 +758,69 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
         }
+        if constexpr (SORTED) {
+            if (a.tabu && wave != 0) {
+                // ---- side effects of the reference's scan of the tabu list (two_opt_tabu_list.hpp, tabu_side), by the seven
+                // waves that would otherwise wait for the first one's exchange: thread t of them, cluster-wide, takes the list
+                // entries t, t + C x 448, ...; succ / pred come from the replica (internal ids; the stamps are indexed by
+                // node ids).  The move of this sweep is applied after the barrier that follows.
+                auto nsucc = [&](int v) { int p2 = (int)pos[a.iid[v]] + 1; if (p2 == n) p2 = 0; return a.gid[(int)order[p2]]; };
+                auto npred = [&](int v) { int p2 = (int)pos[a.iid[v]]; p2 = p2 == 0 ? n - 1 : p2 - 1; return a.gid[(int)order[p2]]; };
+                auto live_v = [&](int sv) { return sv != 0 && !(a.iter - sv > a.tenure); };
+                auto live = [&](int x, int y) { return live_v(a.tabu[udir_pos(x, y, n)]); };
+                const int m = min(*a.tabu_list_n, a.tabu_list_cap);
+                for (int k = c * (kClThreads - 64) + tid - 64; k < m; k += C * (kClThreads - 64)) {
+                    const int2 e = a.tabu_list[k];
+                    const int u = e.x, v = e.y;
+                    int *sp = a.tabu + udir_pos(u, v, n);
+                    const int sv = *sp;
+                    if (sv == 0) continue;
+                    const int su = nsucc(u), s2 = nsucc(v);
+                    const bool uv = su == v, vu = s2 == u;
+                    if (!live_v(sv)) {
+                        if (!uv && !vu) *sp = 0;
+                        else {
+                            // expired stamp on the tour edge x -> y: cleared iff the reference's chain reaches it
+                            const int x = uv ? u : v, y = uv ? v : u, px = npred(x);
+                            bool looked = false;
+                            for (int b = x + 1; b < n && !looked; ++b) looked = b != y && b != px && !live(x, b);
+                            for (int q = 0; q < x && !looked; ++q) looked = q != px && q != y && !live(q, x) && !live(q, nsucc(q));
+                            if (!looked) looked = y < px && px != nsucc(y) && !live(y, px) && !live(y, nsucc(y)) && !live(px, x);
+                            if (looked) *sp = 0;
+                        }
+                        continue;
+                    }
+                    if (!uv && !vu) {
+                        const int fu = live(u, su) ? 1 : 0, fv = live(v, s2) ? 1 : 0;
+                        tabu_cnt += 1 - fu - fv + fu * fv;
+                    } else {
+                        tabu_cnt += n - 3;
+                        const int y = uv ? v : u, sy = uv ? s2 : su;
+                        if (live(y, sy)) tabu_cnt += 1;
+                        // live tour edges of this sweep, cluster-wide (the C(|F|, 2) term): complete before this workgroup
+                        // publishes its NEXT candidate; the first workgroup reads the count after that exchange
+                        atomicAdd(a.tabu_side + 1 + slot_cur, 1ull);
+                        __threadfence();
+                    }
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const int aa = o ? v : u, w = o ? u : v, sa = o ? s2 : su;
+                        const int b = npred(w);
+                        if (b != aa && aa < b && b != sa && !live(aa, b) && !live(aa, sa) && !live(b, w)) tabu_cnt += 1;
+                    }
+                }
+            }
+        }
         if (!probe_hit) {
             __syncthreads();
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
         }
         if constexpr (SORTED) {
-            if (a.tabu && c == 0 && tid == 0) {   // every workgroup's adds of this sweep came before its candidate
-                unsigned long long *fp = a.tabu_side + 1 + (sweeps & 1);
+            if (a.tabu && c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
+                // (three slots in turn: the slot read and zeroed here is next added to two sweeps on, by workgroups that have
+                // seen this one's next candidate -- with two, a fast workgroup's adds of the next sweep could slip in before the read)
+                unsigned long long *fp = a.tabu_side + 1 + slot_prev;
                 const long long f = (long long)atomicAdd(fp, 0ull);
                 if (f) { tabu_cnt -= f * (f - 1) / 2; atomicExch(fp, 0ull); __threadfence(); }   // zero again before this thread publishes the next candidate
             }
