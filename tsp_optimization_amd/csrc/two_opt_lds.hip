@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
                                                              int rmax, int count_evals, int max_iters, double margin, double prune,
-                                                             int probe) {
+                                                             int probe, int probe2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
     double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     long long *s_ll = reinterpret_cast<long long *>(scratch + 256);  // 16
     double *s_chunk = reinterpret_cast<double *>(scratch + 384);  // 64 doubles (fcost cost recompute)
     int4 *s_win = reinterpret_cast<int4 *>(scratch + 384);        // 8 (FIRST, the probe's vote): shares the chunk, which only BEST uses
+    int *s_flag = reinterpret_cast<int *>(scratch + 384 + 384);   // FIRST: second probe round
 
     const int tour = blockIdx.x;
     const int tid = threadIdx.x;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     s_k[wv] = hb;
                     s_ll[wv] = (long long)ab;
                 }
+                if (tid == 0) *s_flag = 1 << 20;   // second round: smallest m with a hit so far
                 if (hb && ln == __builtin_ctzll(hb)) {
                     s_d[wv] = delta; s_k[8 + wv] = make_key(i, j);
                     s_win[wv] = make_int4((int)pos[i], (int)pos[j], win_a1, win_b1);   // the move needs no further look at the tour
@@ -214,6 +216,74 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     }
                 }
                 if (!probe_hit) { si = ei; sj = ej; }
+                // ---- second round: the 4 096 pairs after those, up to eight per thread (thread t at 512 (m + 1) + t, m = 0 .. 7).
+                // 57 % of the hits the first 512 pairs miss lie here (oracle trace, see above), and a rows x columns scan
+                // with its votes, arg-min and counting pass costs three times this.  A wave stops after the first m in which
+                // one of its lanes has a hit (every pair of a later m comes later in scan order), and after the first m any wave
+                // has reported one (s_flag, an LDS minimum); the adjacent pairs up to the winner are counted per thread into
+                // adj_acc (summed once per launch).  Rows of >= 591 columns only: the 4 608 pairs then span at most nine rows
+                // and never reach the end of the sweep.
+                if (!probe_hit && probe2 && ci <= n - 600) {
+                    constexpr int NWV = kLdsThreads / 64, R2 = 8;
+                    long long *s_t2 = s_ll + 8;                                  // per wave: smallest pair number with a hit
+                    double *s_d2 = s_d + 8;
+                    int4 *s_win2 = s_win + 8;
+                    u64 *s_key2 = reinterpret_cast<u64 *>(s_win + 16);
+                    const int ln = tid & 63, wv = tid >> 6;
+                    unsigned adjm = 0;
+                    bool hit = false;
+                    int hm = 0, hi_ = 0, hj_ = 0, ha1 = 0, hb1 = 0;
+                    double hd = 0.0;
+                    for (int m = 0; m < R2; ++m) {
+                        if (m > *(volatile int *)s_flag) break;   // an earlier m has a hit somewhere in the workgroup
+                        int i = ci, j = cj + 1 + kLdsThreads * (m + 1) + tid;
+                        while (j >= n) { j = j - n + i + 2; i += 1; }
+                        const NodeRec ri = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, i);
+                        const NodeRec rj = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, j);
+                        const bool adjp = j == ri.succ || rj.succ == i;   // heuristics.c:471
+                        if (adjp) adjm |= 1u << m;
+                        else {
+                            const double delta = pair_delta<WT, INT>(ri, rj);
+                            if (delta < 0) { hit = true; hm = m; hi_ = i; hj_ = j; ha1 = ri.succ; hb1 = rj.succ; hd = delta; }
+                        }
+                        if (__any(hit)) { if (ln == 0) atomicMin(s_flag, m); break; }
+                    }
+                    const unsigned long long hb2 = __ballot(hit);
+                    if (ln == 0) s_t2[wv] = hb2 ? (long long)kLdsThreads * (0 + 1) : (long long)1 << 40;   // patched below by the hit lane
+                    if (hb2 && ln == __builtin_ctzll(hb2)) {
+                        s_t2[wv] = (long long)kLdsThreads * (hm + 1) + tid;
+                        s_d2[wv] = hd; s_key2[wv] = make_key(hi_, hj_);
+                        s_win2[wv] = make_int4((int)pos[hi_], (int)pos[hj_], ha1, hb1);
+                    }
+                    __syncthreads();
+                    {
+                        const int lw = ln & (NWV - 1);
+                        const long long tw = s_t2[lw];
+                        const double dw = s_d2[lw];
+                        const u64 kw = s_key2[lw];
+                        const int4 ww = s_win2[lw];
+                        const u64 tk = wave_min_u64(((u64)tw << 3) | (u64)lw);   // lanes 8 .. 63 repeat lanes 0 .. 7
+                        const long long twin = (long long)(tk >> 3);
+                        const int fw = (int)(tk & 7);
+                        if (twin < ((long long)1 << 40)) {
+                            probe_hit = true;
+                            bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dw), fw), __builtin_amdgcn_readlane(__double2loint(dw), fw));
+                            const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
+                            const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(kw >> 32), fw);
+                            key = ((u64)khi << 32) | klo;
+                            win.x = __builtin_amdgcn_readlane(ww.x, fw); win.y = __builtin_amdgcn_readlane(ww.y, fw);
+                            win.z = __builtin_amdgcn_readlane(ww.z, fw); win.w = __builtin_amdgcn_readlane(ww.w, fw);
+                            // this thread's adjacent pairs before the winner (the first 512 pairs' are in probe_adj already)
+#pragma unroll
+                            for (int m = 0; m < R2; ++m)
+                                if ((adjm >> m & 1u) && (long long)kLdsThreads * (m + 1) + tid < twin) adj_acc += 1;
+                        } else {   // nothing in these 2 560 pairs: the scan goes on behind them
+                            int ei2 = ci, ej2 = cj + kLdsThreads * (R2 + 1);
+                            while (ej2 >= n) { ej2 = ej2 - n + ei2 + 2; ei2 += 1; }
+                            si = ei2; sj = ej2;
+                        }
+                    }
+                }
             }
             row_lo = si; row_hi = min(si + chunk, n - 1);
 #ifdef TSP_STAMPS
@@ -415,7 +485,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             }
         } else {
             const long long r_new = pair_rank(ni, nj, n);
-            scanned += probe_hit ? kLdsThreads : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
+            scanned += probe_hit ? r_new - r_cur : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
             evals += r_new - r_cur - adj;
             if (found) probe_on = r_new - r_cur <= probe;   // (also switching it off after a step without a hit: measured, slower)
             r_cur = r_new;
@@ -471,7 +541,7 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 65536));
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 65536), env_int("TSP_LDS_PROBE2", 1));
     return hipGetLastError();
 }
 
