@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 // has reported one (s_flag, an LDS minimum); the adjacent pairs up to the winner are counted per thread into
                 // adj_acc (summed once per launch).  Rows of >= 591 columns only: the 4 608 pairs then span at most nine rows
                 // and never reach the end of the sweep.
-                if (!probe_hit && probe2 && ci <= n - 600) {
+                if (!probe_hit && probe2 && ci <= n - 600) {   // (4 and 8 rounds measure alike, 12 and more lose: configs[4] 227 / 227 / 229 / 233 / 242 ms at 4 / 8 / 12 / 16 / 24)
                     constexpr int NWV = kLdsThreads / 64, R2 = 8;
                     long long *s_t2 = s_ll + 8;                                  // per wave: smallest pair number with a hit
                     double *s_d2 = s_d + 8;
