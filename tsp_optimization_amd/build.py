@@ -3,7 +3,7 @@ import os
 import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(PKG, "lib")
+LIB_DIR = os.environ.get("TSP_LIB_DIR") or os.path.join(PKG, "lib")   # TSP_LIB_DIR: a diagnostic or A/B build (tools/)
 
 
 def lib_path(name="libtsp_hip.so"):

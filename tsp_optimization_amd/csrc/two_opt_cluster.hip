@@ -296,8 +296,11 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
     return true;
 }
 
-template <int WT, bool INT, int MODE, typename CT, bool SORTED>
+// TABU: a best-improvement run with a tabu list (sorted scan only) -- a variant of its own, so that the plain descent carries
+// none of it (as run-time branches on a pointer the list code cost the plain sweep 2.5 %: 11.3 -> 11.6 us at n = 10 000)
+template <int WT, bool INT, int MODE, typename CT, bool SORTED, bool TABU = false>
 __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArgs a) {
+    static_assert(!TABU || SORTED, "tabu lists ride on the sorted scan");
     static_assert(!SORTED || (MODE == TSP_2OPT_BEST && has_root_filter<WT>()), "the sorted scan is a best-improvement sweep on a sqrt metric");
     constexpr bool BEST = MODE == TSP_2OPT_BEST;
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         double bd = 0.0;
         u64 key = kNoKey;
         unsigned ipair = 0;
-        const int slot_cur = (int)(sweeps % 3), slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
+        const int slot_cur = TABU ? (int)(sweeps % 3) : 0, slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
         int si = ci, sj = cj;    // FIRST: where the tiles scan starts (the probe moves it on when it finds nothing)
         bool probe_hit = false;
         long long probe_adj = 0;
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                         const u64 kk = make_key(min(gi, gj), max(gi, gj));
                                         if (delta < bd || kk < key) {
                                             bool is_tabu = false;
-                                            if (a.tabu) {   // tabusearch.c:137-149 on node ids, a = the lower one, lazy clears included
+                                            if constexpr (TABU) {   // tabusearch.c:137-149 on node ids, a = the lower one, lazy clears included
                                                 const bool lo = gi < gj;
                                                 const int i = lo ? gi : gj, jn = lo ? gj : gi;
                                                 const int a1 = a.gid[lo ? ri.succ : rj.succ], b1 = a.gid[lo ? rj.succ : ri.succ];
@@ -758,8 +761,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
         }
-        if constexpr (SORTED) {
-            if (a.tabu && wave != 0) {
+        if constexpr (TABU) {
+            if (wave != 0) {
                 // ---- side effects of the reference's scan of the tabu list (two_opt_tabu_list.hpp, tabu_side), by the seven
                 // waves that would otherwise wait for the first one's exchange: thread t of them, cluster-wide, takes the list
                 // entries t, t + C x 448, ...; succ / pred come from the replica (internal ids; the stamps are indexed by
@@ -816,8 +819,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
         }
-        if constexpr (SORTED) {
-            if (a.tabu && c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
+        if constexpr (TABU) {
+            if (c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
                 // (three slots in turn: the slot read and zeroed here is next added to two sweeps on, by workgroups that have
                 // seen this one's next candidate -- with two, a fast workgroup's adds of the next sweep could slip in before the read)
                 unsigned long long *fp = a.tabu_side + 1 + slot_prev;
@@ -949,8 +952,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         if (w_ex) __hip_atomic_fetch_add((gll *)&st->exact_pairs, w_ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w_st) __hip_atomic_fetch_add((gll *)&st->staged_recs, w_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (SORTED) {
-        if (a.tabu && !failed) {   // uniform: every thread of the workgroup takes part in the sum
+    if constexpr (TABU) {
+        if (!failed) {   // uniform: every thread of the workgroup takes part in the sum
             __syncthreads();
             const long long tot = block_sum<long long>(tabu_cnt, s_ll);
             if (tid == 0 && tot) atomicAdd(a.tabu_side, (unsigned long long)tot);
@@ -1021,10 +1024,10 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     return p;
 }
 
-template <int WT, bool INT, int MODE, typename CT, bool SORTED>
+template <int WT, bool INT, int MODE, typename CT, bool SORTED, bool TABU = false>
 hipError_t cl_launch_k(tsp_dev_tours *t, const ClusterArgs &a, size_t lds) {
     hipStream_t s = t->inst->ctx->stream;
-    auto k = k_cluster_two_opt<WT, INT, MODE, CT, SORTED>;
+    auto k = k_cluster_two_opt<WT, INT, MODE, CT, SORTED, TABU>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(t->B * a.C), dim3(kClThreads), lds, s, a);
@@ -1036,6 +1039,7 @@ hipError_t cl_launch(tsp_dev_tours *t, int mode, const ClPlan &p, const ClusterA
     using CT = std::conditional_t<cl_float_coords<WT>(), float2, double2>;
     if (mode == TSP_2OPT_FIRST) return cl_launch_k<WT, INT, TSP_2OPT_FIRST, CT, false>(t, a, p.lds);
     if constexpr (has_root_filter<WT>()) {
+        if (p.sorted && a.tabu) return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, true, true>(t, a, p.lds);
         if (p.sorted) return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, true>(t, a, p.lds);
     }
     return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, false>(t, a, p.lds);
