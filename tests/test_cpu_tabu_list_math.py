@@ -103,3 +103,11 @@ def test_closed_form_equals_the_literal_scan(seed):
     e2, s2 = closed_form(n, succ, stamps, it, tenure)
     assert e1 == e2
     assert (s1 == s2).all()
+    # and the C oracle's alg_2opt_tabu (the checker of the GPU tests) does the same in its first sweep: a third, independent
+    # statement of tabusearch.c:83-92,137-149 (the delta does not enter either number)
+    from oracle import oracle as O
+    xy = rng.integers(0, 1000, size=(n, 2)).astype(np.float64)
+    st32 = stamps.astype(np.int32)
+    _, _, _, ost, _, _ = O.two_opt_best(xy, O.EUC_2D, succ.astype(np.int32), tabu=st32, iter_=it, tenure=tenure, max_sweeps=1)
+    assert ost["sweeps"] == 1 and ost["evals"] == e1
+    assert (st32 == s1).all()
