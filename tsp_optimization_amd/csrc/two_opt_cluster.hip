@@ -59,6 +59,8 @@ __device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: uni
 struct ClusterArgs {
     const double2 *coord;   // internal numbering: node order (tiles) or Hilbert rank order incl. padding (sorted)
     int *orders;            // B x n: node (caller's numbering) at tour position p
+    int *poss;              // B x n: position of node v, written back with the tour
+    unsigned epoch0;        // exchange epochs of this launch start above this (even): no zeroing of the exchange area between launches
     TourState *states;
     const int *gid;         // sorted: internal id -> node
     const int *iid;         // sorted: node -> internal id
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 #ifdef TSP_STAMPS
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #endif
-    unsigned xep = 0;        // exchanges so far (their epoch: a step decided by the probe has none)
+    unsigned xep = a.epoch0;   // exchange epochs (a step decided by the probe has none); slots hold smaller ones from earlier launches
     bool probe_on = true;    // FIRST: the last hit lay close to the cursor (every workgroup keeps the same value)
     for (int iter = 0; iter < a.max_iters && !done; ++iter) {
         int row_lo = 0, row_hi = n - 1;
@@ -962,10 +964,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
     if (failed || c != 0) return;
     __syncthreads();
+    int *pos_g = a.poss + (size_t)tour * n;
     for (int p = tid; p < n; p += kClThreads) {
         int v = (int)order[p];
         if constexpr (SORTED) v = a.gid[v];
         order_g[p] = v;
+        pos_g[v] = p;
     }
     if (tid == 0) {
         st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
@@ -1047,7 +1051,7 @@ hipError_t cl_launch(tsp_dev_tours *t, int mode, const ClPlan &p, const ClusterA
 }  // namespace
 
 // implemented in two_opt_grid.hip
-int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out, bool pos_written = false);
 
 #ifdef TSP_STAMPS
 // diagnostic: per workgroup of tour 0, 100 MHz ticks per phase {tests, scan, block arg-min, exchange, counters, move, -, steps}; resets
@@ -1125,6 +1129,8 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         const size_t words = (size_t)B * 2 * C * kClSlotGranules + 2;   // + the error word
         TSP_HIP_TRY(hipMalloc(&t->d_cl_slots, sizeof(unsigned long long) * words));
         t->cl_slot_words = words;
+        TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * words, s));
+        t->cl_epoch = 0;
         t->cl_C = C;
     }
     if (p.sorted && !t->d_cl_pairtab) {
@@ -1155,6 +1161,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.gbox = inst->d_gbox;
     a.pairtab = t->d_cl_pairtab;
     a.slots = t->d_cl_slots;
+    a.poss = t->d_pos;
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
     a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;
@@ -1194,7 +1201,14 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
             a.max_iters = (int)std::min<int64_t>(launch_iters, max_steps - queued);
         }
         queued += a.max_iters;
-        TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
+        // exchange epochs run on from launch to launch (a tag of an earlier launch never equals a later epoch), so the area is
+        // zeroed only when it is new, after a failed launch, and before the 32-bit epoch would wrap
+        if ((unsigned long long)t->cl_epoch + (unsigned)a.max_iters + 4ull >= 0xffffffffull) {
+            TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
+            t->cl_epoch = 0;
+        }
+        a.epoch0 = t->cl_epoch;
+        t->cl_epoch += ((unsigned)a.max_iters + 3u) & ~1u;   // even: the parity of an epoch picks the half of the area
         hipError_t e = hipSuccess;
         TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
         if (e != hipSuccess) { tsp::set_last_error("k_cluster_two_opt launch", e, __FILE__, __LINE__); return TSP_DEV_E_HIP; }
@@ -1204,6 +1218,8 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         TSP_HIP_TRY(hipStreamSynchronize(s));
         const int err = *t->h_cl_err;
         if (err) {
+            (void)hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s);   // the error word too
+            t->cl_epoch = 0;
             tsp::set_last_error("k_cluster_two_opt: a workgroup of the cluster was not resident (exchange gave up)",
                                 hipErrorLaunchFailure, __FILE__, __LINE__);
             if (fell_through) *fell_through = 1;
@@ -1216,6 +1232,6 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     }
     bool unfinished = status == TSP_TIME_LIMIT_EXCEEDED;
     for (int b = 0; b < B; ++b) unfinished = unfinished || !t->h_state[b].done;
-    const int rc = tsp_grid_after_external_run(t, mode, unfinished);
+    const int rc = tsp_grid_after_external_run(t, mode, unfinished, /*pos_written=*/true);
     return rc ? rc : status;
 }

@@ -419,9 +419,9 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
 // that were cut short their recomputed cost (tabusearch.c:168-172).
 // Queued, not waited for (everything that follows is ordered behind it on the engine's stream) -- except for the recomputed
 // cost of a run that was cut short, which the caller reads.
-int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out) {
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out, bool pos_written) {
     hipStream_t s = t->inst->ctx->stream;
-    hipLaunchKernelGGL(k_build_pos, dim3((t->n + 255) / 256, t->B), dim3(256), 0, s, t->d_order, t->d_pos, t->n);
+    if (!pos_written) hipLaunchKernelGGL(k_build_pos, dim3((t->n + 255) / 256, t->B), dim3(256), 0, s, t->d_order, t->d_pos, t->n);
     if (timed_out && mode == TSP_2OPT_BEST) {
         launch_tour_cost(t, &t->d_state[0].obj, sizeof(TourState));
         TSP_HIP_TRY(hipStreamSynchronize(s));

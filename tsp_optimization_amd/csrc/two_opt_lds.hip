@@ -560,7 +560,7 @@ hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_it
 }  // namespace
 
 // implemented in two_opt_grid.hip
-int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out);
+int tsp_grid_after_external_run(tsp_dev_tours *t, int mode, int timed_out, bool pos_written = false);
 
 #ifdef TSP_STAMPS
 extern "C" int tsp_dev_debug_lds(unsigned long long *out8) {
