@@ -343,12 +343,29 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     int *order_g = a.orders + (size_t)tour * n;
     gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * C * kClSlotGranules;
 
-    for (int v = tid; v < nid; v += kClThreads) coord[v] = ClCoord<CT>::make(a.coord[v], a.org_x, a.org_y);
-    for (int p = tid; p < n; p += kClThreads) {
-        int w = order_g[p];
-        if constexpr (SORTED) w = a.iid[w];
-        order[p] = (idx_t)w;
-        pos[w] = (idx_t)p;
+    // the replica: eight loads per thread in flight at a time (a launch loads 120 KB per workgroup at n = 10 000; one load per
+    // thread and trip was ~40 dependent memory latencies -- most of the fixed cost of a short resident run)
+    constexpr int LU = 8;
+    for (int v0 = tid; v0 < nid; v0 += LU * kClThreads) {
+        double2 cv[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) { const int v = v0 + u * kClThreads; cv[u] = a.coord[v < nid ? v : 0]; }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) { const int v = v0 + u * kClThreads; if (v < nid) coord[v] = ClCoord<CT>::make(cv[u], a.org_x, a.org_y); }
+    }
+    for (int p0 = tid; p0 < n; p0 += LU * kClThreads) {
+        int w[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) { const int p = p0 + u * kClThreads; w[u] = order_g[p < n ? p : 0]; }
+        if constexpr (SORTED) {
+#pragma unroll
+            for (int u = 0; u < LU; ++u) w[u] = a.iid[w[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kClThreads;
+            if (p < n) { order[p] = (idx_t)w[u]; pos[w[u]] = (idx_t)p; }
+        }
     }
     if constexpr (SORTED) {
         for (int g = tid; g < ng; g += kClThreads) gbox[g] = ClCoord<CT>::box(a.gbox[g], a.org_x, a.org_y);
@@ -965,11 +982,19 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if (failed || c != 0) return;
     __syncthreads();
     int *pos_g = a.poss + (size_t)tour * n;
-    for (int p = tid; p < n; p += kClThreads) {
-        int v = (int)order[p];
-        if constexpr (SORTED) v = a.gid[v];
-        order_g[p] = v;
-        pos_g[v] = p;
+    for (int p0 = tid; p0 < n; p0 += LU * kClThreads) {
+        int v[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) { const int p = p0 + u * kClThreads; v[u] = (int)order[p < n ? p : 0]; }
+        if constexpr (SORTED) {
+#pragma unroll
+            for (int u = 0; u < LU; ++u) v[u] = a.gid[v[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int p = p0 + u * kClThreads;
+            if (p < n) { order_g[p] = v[u]; pos_g[v[u]] = p; }
+        }
     }
     if (tid == 0) {
         st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
@@ -1032,8 +1057,13 @@ template <int WT, bool INT, int MODE, typename CT, bool SORTED, bool TABU = fals
 hipError_t cl_launch_k(tsp_dev_tours *t, const ClusterArgs &a, size_t lds) {
     hipStream_t s = t->inst->ctx->stream;
     auto k = k_cluster_two_opt<WT, INT, MODE, CT, SORTED, TABU>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t granted_dev[64] = {0};   // per kernel variant and device: the attribute call is not free and a resident driver launches thousands of times
+    size_t &granted = granted_dev[t->inst->ctx->device & 63];
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+    }
     hipLaunchKernelGGL(k, dim3(t->B * a.C), dim3(kClThreads), lds, s, a);
     return hipGetLastError();
 }

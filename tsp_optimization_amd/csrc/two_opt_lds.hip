@@ -538,8 +538,13 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
     hipStream_t s = t->inst->ctx->stream;
     const size_t bytes = lds_bytes_needed(t->n, CACHE);
     auto k = k_lds_two_opt<WT, INT, MODE, CACHE>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return e;
+    static size_t granted_dev[64] = {0};   // per kernel variant and device
+    size_t &granted = granted_dev[t->inst->ctx->device & 63];
+    if (bytes > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        granted = bytes;
+    }
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
                        rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 65536), env_int("TSP_LDS_PROBE2", 1));
     return hipGetLastError();
