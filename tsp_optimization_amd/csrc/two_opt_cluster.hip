@@ -60,6 +60,7 @@ struct ClusterArgs {
     const double2 *coord;   // internal numbering: node order (tiles) or Hilbert rank order incl. padding (sorted)
     int *orders;            // B x n: node (caller's numbering) at tour position p
     int *poss;              // B x n: position of node v, written back with the tour
+    long long *stats_part;  // B x 256 x 4: executed-work counters per workgroup {lane pairs, tier-1 pairs, delta expressions, staged records}
     unsigned epoch0;        // exchange epochs of this launch start above this (even): no zeroing of the exchange area between launches
     TourState *states;
     const int *gid;         // sorted: internal id -> node
@@ -964,12 +965,20 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][7] += steps - st->steps; }
     if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
 #endif
-    if (!failed && lane == 0) {   // executed-work counters: every workgroup adds its share (the fields are written by nobody else)
-        using gll = __attribute__((address_space(1))) long long;
-        if (w_lane) __hip_atomic_fetch_add((gll *)&st->lane_pairs, w_lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w_t1) __hip_atomic_fetch_add((gll *)&st->tier1_pairs, w_t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w_ex) __hip_atomic_fetch_add((gll *)&st->exact_pairs, w_ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (w_st) __hip_atomic_fetch_add((gll *)&st->staged_recs, w_st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!failed) {
+        // executed-work counters: every workgroup adds its share to a slot of its own (read and summed by tsp_dev_tours_download).
+        // As 8 x 256 atomics on four words of one cache line they were the largest single item of a short launch (~70 us of 86).
+        __syncthreads();
+        if (lane == 0) { s_ll[wave] = w_lane; s_ll[8 + wave] = w_t1; }
+        if (lane == 0) { s_k[wave] = (u64)w_ex; s_k[8 + wave] = (u64)w_st; }
+        __syncthreads();
+        if (tid < 4) {
+            long long tot = 0;
+            for (int w = 0; w < kClWaves; ++w)
+                tot += tid == 0 ? s_ll[w] : (tid == 1 ? s_ll[8 + w] : (tid == 2 ? (long long)s_k[w] : (long long)s_k[8 + w]));
+            a.stats_part[((size_t)tour * 256 + c) * 4 + tid] += tot;
+        }
+        __syncthreads();
     }
     if constexpr (TABU) {
         if (!failed) {   // uniform: every thread of the workgroup takes part in the sum
@@ -1192,6 +1201,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.pairtab = t->d_cl_pairtab;
     a.slots = t->d_cl_slots;
     a.poss = t->d_pos;
+    if (!t->d_cl_stats) {
+        TSP_HIP_TRY(hipMalloc(&t->d_cl_stats, sizeof(long long) * (size_t)B * 256 * 4));
+        TSP_HIP_TRY(hipMemsetAsync(t->d_cl_stats, 0, sizeof(long long) * (size_t)B * 256 * 4, s));
+    }
+    a.stats_part = t->d_cl_stats;
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
     a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;

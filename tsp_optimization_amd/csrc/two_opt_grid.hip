@@ -738,7 +738,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_state_base); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
     (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
-    (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab);
+    (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab); (void)hipFree(t->d_cl_stats);
     (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result); (void)hipHostFree(t->h_cl_err);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
@@ -761,6 +761,7 @@ int tsp_dev_tours_reset(tsp_dev_tours *t) {
         t->h_state[b] = z;
     }
     t->slot = 0; t->d_state = t->d_state_base;
+    if (t->d_cl_stats) TSP_HIP_TRY(hipMemsetAsync(t->d_cl_stats, 0, sizeof(long long) * (size_t)B * 256 * 4, s));
     TSP_HIP_TRY(hipMemcpyAsync(t->d_state, t->h_state, sizeof(TourState) * (size_t)B, hipMemcpyHostToDevice, s));
     TSP_HIP_TRY(hipStreamSynchronize(s));
     TSP_HIP_TRY(hipGetLastError());
@@ -803,6 +804,11 @@ int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t
         order.resize((size_t)B * n);
         TSP_HIP_TRY(hipMemcpyAsync(order.data(), t->d_order, order.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     }
+    std::vector<long long> part;   // the CLUSTER engine's executed-work counters, one slot per workgroup
+    if (stats && t->d_cl_stats) {
+        part.resize((size_t)B * 256 * 4);
+        TSP_HIP_TRY(hipMemcpyAsync(part.data(), t->d_cl_stats, part.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
+    }
     TSP_HIP_TRY(hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b) {
         if (succ) {
@@ -817,10 +823,14 @@ int tsp_dev_tours_download(tsp_dev_tours *t, int *succ, int succ_stride, int64_t
             o.sweeps = z.sweeps; o.evals = z.evals; o.moves = z.moves; o.reversed = z.reversed;
             o.pairs_scanned = z.pairs_scanned; o.steps = z.steps;
             o.seconds = 0.0; o.device_ms = t->device_ms;   // the last tsp_dev_tours_run_engine (host-tour calls overwrite both)
-            const bool counted = z.lane_pairs > 0 || z.exact_pairs > 0;   // the CLUSTER engine counts what it executes
-            o.lane_pairs = counted ? z.lane_pairs : z.pairs_scanned;
-            o.tier1_pairs = counted ? z.tier1_pairs : -1; o.exact_pairs = counted ? z.exact_pairs : -1;
-            o.staged_recs = counted ? z.staged_recs : -1;
+            long long cs[4] = {z.lane_pairs, z.tier1_pairs, z.exact_pairs, z.staged_recs};
+            if (!part.empty())
+                for (int w = 0; w < 256; ++w)
+                    for (int k = 0; k < 4; ++k) cs[k] += part[((size_t)b * 256 + w) * 4 + k];
+            const bool counted = cs[0] > 0 || cs[2] > 0;   // the CLUSTER engine counts what it executes
+            o.lane_pairs = counted ? cs[0] : z.pairs_scanned;
+            o.tier1_pairs = counted ? cs[1] : -1; o.exact_pairs = counted ? cs[2] : -1;
+            o.staged_recs = counted ? cs[3] : -1;
         }
     }
     return TSP_OK;
