@@ -338,6 +338,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     unsigned *s_ip = reinterpret_cast<unsigned *>(scratch + 480);      // 8: the waves' winners (internal pairs)
     int *s_nitems = reinterpret_cast<int *>(scratch + 476);   // the workgroup's own winner (before the exchange)
     double *s_chunk = reinterpret_cast<double *>(scratch + 512);       // 64 doubles (fcost cost recompute)
+    float4 *s_rowsf = reinterpret_cast<float4 *>(scratch + 512);       // tiles scan, float replica: x, y, edge length of the tile's rows (shares the chunk: that is used at the end of a run only)
 
     TourState *st = a.states + tour;
     if (st->done) return;
@@ -706,7 +707,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 if (b * kClThreads + kClThreads - 1 <= jmin) continue;
                 CL_T(8);
                 __syncthreads();
-                if (tid < nr) s_rows[tid] = cl_node<WT, INT, CT>(coord, order, pos, n, rb + tid);
+                constexpr bool F32T0 = std::is_same<CT, float2>::value && has_root_filter<WT>();
+                if (tid < nr) {
+                    const NodeRec rr = cl_node<WT, INT, CT>(coord, order, pos, n, rb + tid);
+                    s_rows[tid] = rr;
+                    if constexpr (F32T0) s_rowsf[tid] = make_float4((float)rr.x, (float)rr.y, (float)rr.ds, 0.f);
+                }
                 NodeRec rj;
                 const bool act = j < n && j > rb;
                 if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
@@ -716,7 +722,59 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 if (tid == 0) prof[11] += 1;
 #endif
                 w_lane += (long long)nr * __popcll(__ballot(act));
-                {
+                if constexpr (F32T0) {
+                    // Integer coordinates (exact as floats): the new-edge bound in fp32 FIRST, its rounding paid for in slack (s may
+                    // come out 2^-22 low, T -- below 2^23 -- is taken 2 units high, as in the sorted scan), before anything else is
+                    // looked at: on a constructed tour it sends > 99 % of the pairs home after six fp32 operations, and the row's
+                    // full record, the adjacency / cursor / key tests and the fp64 tiers are for the survivors only.  A sweep that
+                    // finds nothing (every first-improvement descent ends with one, HEU_VNS runs five or six per round) is this loop.
+                    const float cxf = act ? (float)rj.x : 0.f, cyf = act ? (float)rj.y : 0.f, cdf = act ? (float)rj.ds : 0.f;
+                    constexpr int RQ = 4;   // rows per trip: four LDS reads in flight, one vote
+                    for (int r0 = 0; r0 < nr; r0 += RQ) {
+                        float4 rf[RQ];
+                        bool need[RQ];
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) rf[u] = s_rowsf[min(r0 + u, nr - 1)];
+                        const float bf = (float)((BEST ? bd : 0.0) + prune2 + 2.0);
+                        bool any = false;
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) {
+                            const float dx = rf[u].x - cxf, dy = rf[u].y - cyf, T = rf[u].z + cdf + bf;
+                            need[u] = act && r0 + u < nr && fmaf(dx, dx, dy * dy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
+                            any = any || need[u];
+                        }
+                        if (!__any(any)) continue;
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) {
+                            const unsigned long long nm = __ballot(need[u]);
+                            if (!nm) continue;
+                            w_t1 += __popcll(nm);
+                            bool ok = false;
+                            const int i = rb + r0 + u;
+                            const NodeRec ri = s_rows[r0 + u];
+                            const u64 kq = make_key(i, j);
+                            if (need[u]) {
+                                ok = j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                                if constexpr (!BEST) ok = ok && (i > si || j > sj) && kq < key;
+                                const double bound = BEST ? bd : 0.0;
+                                ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + prune2);
+                                if (ok) {
+                                    const double lower = pair_delta_approx<WT>(ri, rj) - a.margin;
+                                    ok = BEST ? lower <= bound : lower < bound;
+                                }
+                            }
+                            w_ex += __popcll(__ballot(ok));
+                            if (ok) {
+                                const double delta = pair_delta<WT, INT>(ri, rj);
+                                if constexpr (!BEST) {
+                                    if (delta < 0) { bd = delta; key = kq; }
+                                } else {
+                                    if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                                }
+                            }
+                        }
+                    }
+                } else {
                     for (int r = 0; r < nr; ++r) {
                         const int i = rb + r;
                         const NodeRec ri = s_rows[r];
