@@ -137,6 +137,7 @@ struct tsp_dev_tours {
     size_t cl_slot_words = 0;
     int cl_C = 0;
     long long *d_cl_stats = nullptr; // B x 256 x 4: the CLUSTER engine's executed-work counters per workgroup (summed at download)
+    bool cl_tabu_plan = false;       // the CLUSTER engine is being asked about / run for a descent with a tabu list
     unsigned cl_epoch = 0;           // exchange epochs handed out so far (they run on from launch to launch)
     int *d_cl_pairtab = nullptr;
     int cl_ntests = 0;

@@ -1107,8 +1107,10 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     if (inst->n > 65534) return p;
     const int wt = inst->wtype;
     p.float_coords = wt == WT_EUC_2D_ICOORD || wt == WT_CEIL_2D_ICOORD || wt == WT_ATT_ICOORD;
+    // (runs with a tabu list take the sorted scan at any size: their list code rides on it, and the alternative reads four
+    // stamps per pair -- two_opt_tabu_list.hpp)
     p.sorted = mode == TSP_2OPT_BEST && inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
-               inst->n >= t->sorted_min_n;
+               (inst->n >= t->sorted_min_n || (t->cl_tabu_plan && inst->n >= 8));
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
     const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs

@@ -442,6 +442,8 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode);
 // list of non-zero stamps is usable (one launch per descent, 11 us per sweep at n = 10 000), else the GRID engine (which
 // works from the list as well when it can, and reads four stamps per pair when it cannot).  sync as tsp_grid_run.
 int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int sync, int *all_done) {
+    struct PlanGuard { tsp_dev_tours *t; ~PlanGuard() { t->cl_tabu_plan = false; } } plan_guard{t};
+    t->cl_tabu_plan = tabu && iter >= 0 && tenure >= 0;   // the cluster's sorted scan at any size (see cl_plan)
     if (tabu && iter >= 0 && tenure >= 0 && t->B == 1 && env_int("TSP_TABU_DENSE", 0) == 0 && env_int("TSP_ENGINE", 0) != 1 &&
         tsp_cluster_fits(t, TSP_2OPT_BEST) && tsp_cluster_sorted(t, TSP_2OPT_BEST)) {
         bool usable = false;
@@ -453,6 +455,7 @@ int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, dou
             int fell = 0;
             const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, all_done, &fell,
                                                tabu, iter, tenure);
+            t->cl_tabu_plan = false;
             if (!fell) {
                 if (status < 0) return status;
                 tabu->last_run_list = true;
