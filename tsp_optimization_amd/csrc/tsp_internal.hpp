@@ -122,7 +122,8 @@ struct tsp_dev_tours {
     size_t partial_per_tour = 0;
     tsp::NodeRec *d_rec = nullptr;   // B x max(n, n_slots) node records, rebuilt before every BEST step (k_recs*)
     double *d_gmax = nullptr;        // B x (ng + 1): longest tour edge leaving a node of the group (sorted sweep)
-    int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep
+    int sorted_min_n = 0;            // BEST sweeps of instances with n >= this use the sorted sweep (GRID engine)
+    int cl_sorted_min_n = 8;         // ... the sorted scan (CLUSTER engine: ahead of its tiles scan from n = 52 up, tools/small_best.py)
     int sweep_blocks = 512;          // k_sweep blocks per tour
     int *d_cl_ticket = nullptr;      // k_sweep: arrival counters per tour x cluster
     int *d_pairtab = nullptr;        // group pairs per cluster of k_sweep blocks (host-built), or nullptr

@@ -1110,7 +1110,7 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     // (runs with a tabu list take the sorted scan at any size: their list code rides on it, and the alternative reads four
     // stamps per pair -- two_opt_tabu_list.hpp)
     p.sorted = mode == TSP_2OPT_BEST && inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
-               (inst->n >= t->sorted_min_n || (t->cl_tabu_plan && inst->n >= 8));
+               (inst->n >= t->cl_sorted_min_n || (t->cl_tabu_plan && inst->n >= 8));
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
     const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs

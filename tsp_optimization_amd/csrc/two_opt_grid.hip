@@ -675,6 +675,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
     t->partial_per_tour = std::max(t->partial_per_tour, (size_t)((inst->n + kScanThreads - 1) / kScanThreads) * t->first_grid_rows);
     t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 1000);
+    t->cl_sorted_min_n = env_int("TSP_SORTED_MIN_N", 8);
     size_t rec_per_tour = (size_t)inst->n;
     size_t cl_words = (size_t)B * 64 * 64;   // k_first: one arrival counter per tour x tile row, 64 ints apart
     if (inst->d_sperm) {
