@@ -100,6 +100,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
               scanned = st->pairs_scanned, steps = st->steps;
     bool probe_on = true;                       // FIRST: the last hit lay within `probe` pairs of the cursor
+    bool after_hit = true;                      // FIRST: the step before found a move (TSP_LDS_PROBE2=1: the second round only then)
     long long adj_acc = 0;                      // this thread's share of the adjacent pairs the reference skipped (heuristics.c:471)
     long long r_cur = pair_rank(ci, cj, n);     // rank of the cursor in scan order
     __syncthreads();
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 // has reported one (s_flag, an LDS minimum); the adjacent pairs up to the winner are counted per thread into
                 // adj_acc (summed once per launch).  Rows of >= 591 columns only: the 4 608 pairs then span at most nine rows
                 // and never reach the end of the sweep.
-                if (!probe_hit && probe2 && ci <= n - 600) {   // (4 and 8 rounds measure alike, 12 and more lose: configs[4] 227 / 227 / 229 / 233 / 242 ms at 4 / 8 / 12 / 16 / 24)
+                if (!probe_hit && probe2 && (probe2 > 1 || after_hit) && ci <= n - 600) {   // (4 and 8 rounds measure alike, 12 and more lose: configs[4] 227 / 227 / 229 / 233 / 242 ms at 4 / 8 / 12 / 16 / 24)
                     constexpr int NWV = kLdsThreads / 64, R2 = 8;
                     long long *s_t2 = s_ll + 8;                                  // per wave: smallest pair number with a hit
                     double *s_d2 = s_d + 8;
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             const long long r_new = pair_rank(ni, nj, n);
             scanned += probe_hit ? r_new - r_cur : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
             evals += r_new - r_cur - adj;
+            after_hit = found;
             if (found) probe_on = r_new - r_cur <= probe;   // (also switching it off after a step without a hit: measured, slower)
             r_cur = r_new;
             if (found) {
