@@ -435,24 +435,30 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             if (!probe_hit) __syncthreads();  // everyone has read pa/pb (and finished the adjacency reads)
             L = pb - pa; if (L < 0) L += n;
             const int half = L >> 1;
-            for (int t = tid; t < half; t += kLdsThreads) {
-                int p = pa + 1 + t; if (p >= n) p -= n;
-                int q = pb - t; if (q < 0) q += n;
-                const idx_t u = order[p], w = order[q];
-                order[p] = w; order[q] = u;
-                pos[w] = (idx_t)p; pos[u] = (idx_t)q;
-            }
             if constexpr (CACHE) {
-                // the edges inside the reversed path keep their lengths and change places: positions
-                // pa+1 .. pb-1 of dsp are reversed; the two new edges leave positions pa and pb
+                // one loop for both reversals (tour positions pa+1 .. pb; the edge lengths between them, positions
+                // pa+1 .. pb-1, which keep their values and change places): all four reads of a trip are in flight together
                 const int inner = (L - 1) >> 1;
-                for (int t = tid; t < inner; t += kLdsThreads) {
+                for (int t = tid; t < half; t += kLdsThreads) {
                     int p = pa + 1 + t; if (p >= n) p -= n;
-                    int q = pb - 1 - t; if (q < 0) q += n;
-                    const float u = dsp[p], w = dsp[q];
-                    dsp[p] = w; dsp[q] = u;
+                    int q = pb - t; if (q < 0) q += n;
+                    int q1 = q - 1; if (q1 < 0) q1 += n;
+                    const idx_t u = order[p], w = order[q];
+                    const bool in = t < inner;
+                    const float du = dsp[p], dw = dsp[q1];
+                    order[p] = w; order[q] = u;
+                    pos[w] = (idx_t)p; pos[u] = (idx_t)q;
+                    if (in) { dsp[p] = dw; dsp[q1] = du; }
                 }
                 if (tid < 2) dsp[tid == 0 ? pa : pb] = new_edge;
+            } else {
+                for (int t = tid; t < half; t += kLdsThreads) {
+                    int p = pa + 1 + t; if (p >= n) p -= n;
+                    int q = pb - t; if (q < 0) q += n;
+                    const idx_t u = order[p], w = order[q];
+                    order[p] = w; order[q] = u;
+                    pos[w] = (idx_t)p; pos[u] = (idx_t)q;
+                }
             }
         }
         __syncthreads();
