@@ -128,6 +128,25 @@ def test_lists_on_instances(eng, ctx, monkeypatch, list_engine, name, ic):
     tb.close(); inst.close()
 
 
+@pytest.mark.parametrize("wt_name,n", [("MAN_2D", 90), ("MAX_2D", 140), ("MAN_2D", 333), ("EUC_2D", 5), ("EUC_2D", 7)])
+def test_lists_outside_the_sorted_sweep(eng, ctx, wt_name, n):
+    """Metrics without the new-edge bound (and tours of fewer than 8 nodes) have no sorted sweep: the tiled step takes the
+    check_tenure chain on its candidates, the side effects come from a launch of their own -- still from the list."""
+    wt = getattr(O, wt_name)
+    rng = np.random.default_rng(n)
+    xy = rand_instance(n, seed=n + 1, hi=2000)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    tb = eng.Tabu(inst)
+    succ = random_tour(n, rng)
+    for it, tenure in ((9, 4), (25, 0)):
+        stamps = nasty_stamps(n, succ, rng, it, tenure, density=1.0) if n >= 8 else \
+            (rng.random(n * (n - 1) // 2) < 0.5).astype(np.int32) * rng.integers(1, it + 1, size=n * (n - 1) // 2).astype(np.int32)
+        succ, _ = run_both(eng, inst, tb, xy, wt, succ, stamps, it, tenure)
+        assert tb.list_info()[1], "the run did not work from the list"
+        succ = random_tour(n, rng)
+    tb.close(); inst.close()
+
+
 def test_list_too_long_falls_back_to_the_scan(eng, ctx, monkeypatch):
     """More non-zero stamps than the list path takes (16 384): the run reads the stamps pair by pair and says so."""
     monkeypatch.setenv("TSP_SORTED_MIN_N", "0")

@@ -59,7 +59,7 @@ for c in range(cases):
         rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=2)
         del os.environ["TSP_LDS_PROBE"]
         ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
-    if 8 <= n <= 220 and wt in (O.EUC_2D, O.ATT, O.CEIL_2D):
+    if 4 <= n <= 220:
         # alg_2opt_tabu with a dense random tabu list (live and expired stamps, tour edges included): the list path
         it, ten = int(rng.integers(2, 40)), int(rng.integers(0, 15))
         stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)

@@ -167,7 +167,7 @@ bool sorted_sweep(const tsp_dev_tours *t) { return sorted_sweep_possible(t) && t
 // This step of this run goes through k_move_recs + k_sweep (with a list: only when tabu_list_prepare said so)
 bool sorted_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
     if (mode != TSP_2OPT_BEST) return false;
-    return tabu ? t->tabu_list_run : sorted_sweep(t);
+    return tabu ? (t->tabu_list_run && sorted_sweep_possible(t) && t->n >= 8) : sorted_sweep(t);
 }
 
 constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: the dense scan (k_step<TABU>)
@@ -176,8 +176,9 @@ constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: t
 // stamps; a compaction once enough cleared entries have piled up) and say whether the run can work from it.
 int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
     *usable = false;
-    // any size: the alternative reads four stamps per pair (60 us per sweep at n = 299 against 19)
-    if (!sorted_sweep_possible(t) || t->B != 1 || !tb->d_list || t->n < 8) return TSP_OK;
+    // any size and any metric: the alternative reads four stamps per pair (60 us per sweep at n = 299 against 19); tours outside
+    // the sorted sweep (metrics without the bound) take the tiled step with the side effects as a launch of their own
+    if (t->B != 1 || !tb->d_list || t->n < 4) return TSP_OK;
     hipStream_t s = t->inst->ctx->stream;
     bool readback = false;
     if (!tb->list_valid) {
@@ -264,7 +265,11 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
         if (a.recs)
             hipLaunchKernelGGL((k_recs<WT, INT>), dim3((t->n + kScanThreads - 1) / kScanThreads, t->B), dim3(kScanThreads), 0, s,
                                t->inst->d_coord, t->d_order, t->d_pos, t->d_state, t->d_rec, t->n);
-        if (tabu)
+        if (tabu && t->tabu_list_run) {   // from the list of non-zero stamps, on a tour outside the sorted sweep
+            hipLaunchKernelGGL(k_tabu_side, dim3(kTabuSideBlocks), dim3(kScanThreads), 0, s, t->d_order, t->d_pos, t->n, t->d_state,
+                               tabu->d_stamp, tabu->d_list, tabu->d_list_n, tabu->list_cap, iter, tenure, tabu->d_tabu_pairs);
+            hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, false, true>), g, dim3(kScanThreads), 0, s, a);
+        } else if (tabu)
             hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, true>), g, dim3(kScanThreads), 0, s, a);
         else
             hipLaunchKernelGGL((k_step<WT, INT, TSP_2OPT_BEST, kBestRJ, false>), g, dim3(kScanThreads), 0, s, a);

@@ -20,6 +20,8 @@
 //   evals    non-adjacent pairs minus the skipped ones, the latter counted once each by the FIRST live check of the
 //            chain: P1 live (a,b); P2 live (a,a1) [rows of nodes whose tour edge is live]; P3 live (b,b1) [their
 //            columns]; P4 live (a,b1) [two pairs per live stamp] -- O(1) per list entry, see tabu_side().
+// Tours outside the sorted sweep (metrics without the bound) get the same treatment through the tiled step: k_step<..., TLIST>
+// for (A), k_tabu_side as a launch of its own for (B).
 // Nothing here changes a result: tests/test_gpu_tabu_list.py runs it against the oracle with dense random lists
 // (stamps on tour edges, live and expired) and compares tours, counters and the whole stamp array.
 #pragma once
@@ -193,6 +195,18 @@ __device__ inline void tabu_side(int *scratch, const TabuTour t, const TabuView 
             atomicExch(side + 2, 0ull);
         }
     }
+}
+
+// The side effects as a launch of their own, in front of a tiled step (k_step<..., TLIST>): tours outside the sorted sweep.
+__global__ __launch_bounds__(kScanThreads) void k_tabu_side(const int *__restrict__ order, const int *__restrict__ pos, int n,
+                                                            const TourState *__restrict__ st, int *stamp, const int2 *__restrict__ list,
+                                                            const int *__restrict__ list_n, int list_cap, int iter, int tenure,
+                                                            unsigned long long *side) {
+    __shared__ long long s_scratch[kScanThreads / 64];
+    if (st->done) return;
+    const TabuTour tt{order, pos, n};
+    const TabuView tv{stamp, n, iter, tenure};
+    tabu_side<kScanThreads>(reinterpret_cast<int *>(s_scratch), tt, tv, list, min(*list_n, list_cap), (int)blockIdx.x, (int)gridDim.x, side);
 }
 
 }  // namespace tsp

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(kScanThreads) void k_arm(const TourState *__restric
 // columns (RJ per lane, registers) from order/pos/coord -- three dependent loads and one sqrt per
 // node, amortised over rows x columns evaluations.  Main loop: lanes own columns, the row record
 // is a wave-uniform LDS broadcast; ~70 fp64 instructions per evaluation, no memory traffic.
-template <int WT, bool INT, int MODE, int RJ, bool TABU>
+// TLIST: a best-improvement run with a tabu list worked from its non-zero entries (two_opt_tabu_list.hpp) on a tour outside
+// the sorted sweep (metrics without the bound): a pair that would become a lane's best goes through the check_tenure chain
+// first; the scan's side effects come from k_tabu_side, launched in front of every step.
+template <int WT, bool INT, int MODE, int RJ, bool TABU, bool TLIST = false>
 __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
+    static_assert(!TLIST || (!TABU && MODE == TSP_2OPT_BEST), "the list variant replaces the per-pair look-ups of a best-improvement sweep");
     constexpr int TJ = kScanThreads * RJ;
 #ifdef TSP_STAMPS
     __shared__ unsigned long long stamps[16];
@@ -116,10 +120,10 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     // (heuristics.c:471 / tabusearch.c:134 exist to skip exactly those).  Non-integer costs keep the test:
     // there (x + y) - x - y can round to a tiny negative.
     constexpr bool EXACT_SUMS = INT || WT == WT_CEIL_2D || WT == WT_CEIL_2D_ICOORD;
-    const bool plain_tile = MODE == TSP_2OPT_BEST && !TABU && FILTER && EXACT_SUMS && c0 >= r1 && c0 + TJ <= n;
+    const bool plain_tile = MODE == TSP_2OPT_BEST && !TABU && !TLIST && FILTER && EXACT_SUMS && c0 >= r1 && c0 + TJ <= n;
     // bounds switched off (TSP_NO_FILTER=1, margins 1e300): every delta expression is executed, and nothing else -- no
     // bound arithmetic that could never exclude a pair.  This is the exhaustive sweep bench.py's roofline.exhaustive times.
-    const bool exhaustive = MODE == TSP_2OPT_BEST && !TABU && FILTER && a.margin > 1e299;
+    const bool exhaustive = MODE == TSP_2OPT_BEST && !TABU && !TLIST && FILTER && a.margin > 1e299;
     if (exhaustive) {
         for (int ib = r0; ib < r1; ib += 2) {   // two rows in flight: the root is a long dependent chain
             const int i0 = ib, i1 = min(ib + 1, r1 - 1);
@@ -215,6 +219,15 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
                     const double delta = pair_delta<WT, INT>(ri, rj[k]);
                     if constexpr (MODE == TSP_2OPT_FIRST) {
                         if (ok[k] && delta < 0 && bi < 0) { bd = delta; bi = i; bj = jc[k]; }  // keep the first in (i, j) order
+                    } else if constexpr (TLIST) {
+                        if (ok[k] && delta < bd) {   // tabusearch.c:137-149 (i < jc[k]: a = i), lazy clears included
+                            const int j = jc[k], a1 = ri.succ, b1 = rj[k].succ;
+                            const bool tb = stamp_is_tabu(a.tabu + udir_pos(i, j, n), a.iter, a.tenure) ||
+                                            stamp_is_tabu(a.tabu + udir_pos(i, a1, n), a.iter, a.tenure) ||
+                                            stamp_is_tabu(a.tabu + udir_pos(j, b1, n), a.iter, a.tenure) ||
+                                            stamp_is_tabu(a.tabu + udir_pos(i, b1, n), a.iter, a.tenure);
+                            if (!tb) { bd = delta; bi = i; bj = j; }
+                        }
                     } else {
                         if (ok[k] && delta < bd) { bd = delta; bi = i; bj = jc[k]; }
                     }
@@ -295,7 +308,7 @@ __global__ __launch_bounds__(kScanThreads) void k_step(const StepArgs a) {
     if (!s_last) return;
     TSP_STAMP(5);
 #ifdef TSP_STAMPS
-    apply_step<WT, INT, MODE, RJ, TABU>(a, tour, row_lo, row_hi, stamps);
+    apply_step<WT, INT, MODE, RJ, TABU>(a, tour, row_lo, row_hi, stamps);   // TLIST: as without a list (k_tabu_fix_evals takes the skipped pairs off)
 #else
     apply_step<WT, INT, MODE, RJ, TABU>(a, tour, row_lo, row_hi);
 #endif
