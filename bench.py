@@ -434,6 +434,32 @@ def main():
         os.environ.pop("TSP_TABU_DENSE", None)
         res["four_stamp_reads_per_pair"]["hbm_frac"] = res["four_stamp_reads_per_pair"]["those_bytes_per_s_GBps"] / HBM_PEAK_GBS
         res["live_stamps"] = live
+        # iterations of tabu() (tabusearch.c:238-309) on resident state: alg_2opt_tabu + incumbent + kick per iteration
+        tb = E.Tabu(inst)
+        tt = E.Tours(inst, 1)
+        tt.upload(s_t[0], o)                      # the local optimum reached above
+        krng = np.random.default_rng(11)
+        best, iters, tenure = float("inf"), 400, 200
+        def one(it):
+            nonlocal best
+            a, b = int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES))
+            rc, obj, best, improved, acc = tt.tabu_iteration(tb, it, tenure, a, b, best)
+            while not acc:
+                acc = tt.tabu_kick(tb, int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES)), it, tenure)
+        for it in range(1, 41):
+            one(it)
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for it in range(41, 41 + iters):
+            one(it)
+        ctx.synchronize()
+        dt = time.perf_counter() - t1
+        _, _, st_d = tt.download()
+        res["tabu_iterations_on_resident_state"] = {"iterations": iters, "seconds": dt, "iterations_per_s": iters / dt,
+                                                    "tenure": tenure, "incumbent": best, "list_entries": tb.list_info()[0],
+                                                    "worked_from_the_list": tb.list_info()[1],
+                                                    "sweeps_per_iteration": (st_d[0]["sweeps"]) / float(iters + 40)}
+        tb.close(); tt.close()
         out["alg_2opt_tabu_with_a_list"] = res
 
     if rank == 0 and world == 1 and not args.no_extras:
