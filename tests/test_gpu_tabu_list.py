@@ -61,12 +61,12 @@ def nasty_stamps(n, succ, rng, iter_, tenure, density):
     return st
 
 
-def run_both(eng, inst, tb, xy, wt, succ0, stamps, it, tenure, integer_cost=1):
+def run_both(eng, inst, tb, xy, wt, succ0, stamps, it, tenure, integer_cost=1, time_limit=-1.0):
     exp_st = stamps.copy()
     _, es, eo, est, _, eprev = O.two_opt_best(xy, wt, succ0, integer_cost=integer_cost, tabu=exp_st, iter_=it, tenure=tenure,
                                               want_prev=True)
     tb.upload(stamps)
-    rc, s, o, st, prev = tb.two_opt(succ0, it, tenure, want_prev=True)
+    rc, s, o, st, prev = tb.two_opt(succ0, it, tenure, want_prev=True, time_limit=time_limit)
     assert rc == 0 and O.is_tour(s)
     assert (s == es).all(), "final tour differs from the oracle's"
     assert o == eo and (prev == eprev).all()
@@ -144,6 +144,22 @@ def test_lists_outside_the_sorted_sweep(eng, ctx, wt_name, n):
         succ, _ = run_both(eng, inst, tb, xy, wt, succ, stamps, it, tenure)
         assert tb.list_info()[1], "the run did not work from the list"
         succ = random_tour(n, rng)
+    tb.close(); inst.close()
+
+
+def test_descent_cut_into_several_launches(eng, ctx, monkeypatch, list_engine):
+    """With a time limit the CLUSTER engine runs a descent as launches of 128 sweeps: the per-sweep counters of the list code
+    (live tour edges, taken off one sweep later) have to carry over the launch boundaries."""
+    monkeypatch.setenv("TSP_SORTED_MIN_N", "0")
+    xy, wt = load_instance("rand1000")
+    n = len(xy)
+    rng = np.random.default_rng(4)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    tb = eng.Tabu(inst)
+    _, succ, _ = O.greedy(xy, wt)
+    stamps = nasty_stamps(n, succ, rng, 30, 8, density=0.3)
+    _, exp = run_both(eng, inst, tb, xy, wt, succ, stamps, 30, 8, time_limit=600.0)   # 163 sweeps without a list: two launches
+    assert tb.list_info()[1]
     tb.close(); inst.close()
 
 
