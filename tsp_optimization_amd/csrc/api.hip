@@ -415,7 +415,9 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         // 1.4-2.6 x faster than GRID in both rules, level with LDS at n = 52, 1.6 x faster at n = 299); eight or more tours: one
         // workgroup per tour (LDS, first improvement) unless that would leave most of the chip idle (C >= 8), best-improvement
         // batches on CLUSTER only with the sorted scan
-        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? (C >= 4 && tsp_cluster_sorted(t, mode)) : C >= 8));
+        // (best-improvement batches: the cluster's sorted scan beats the GRID engine's lock-step launches about 2 x at every batch
+        // size that fits the chip, one workgroup per tour included -- tools/best_batch.py)
+        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : C >= 8));
         if (force && *force == '1') { lds = false; cluster = false; }
         if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
         if (force && *force == '3' && C >= 1) cluster = true;
@@ -461,7 +463,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
 static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const bool want = engine == TSP_ENGINE_CLUSTER ||
-                          (tsp_cluster_fits(t, mode) && (t->B < 8 || tsp_cluster_size(t, mode) >= 8));
+                          (tsp_cluster_fits(t, mode) && (t->B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : tsp_cluster_size(t, mode) >= 8)));
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
             int fell = 0;
