@@ -62,6 +62,23 @@ def test_cluster_sizes_match_oracle(eng, ctx, monkeypatch, C, mode, sorted_scan,
     assert _same(st, est), (st, est)
 
 
+def test_best_improvement_batch_larger_than_the_chip(eng, ctx):
+    """300 tours of berlin52, best improvement, the engine the library picks (CLUSTER, one workgroup per tour, no exchange, more
+    workgroups than CUs: they run in turns) against the oracle, tour by tour."""
+    xy, wt = load_instance("berlin52")
+    n = len(xy)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    rng = np.random.default_rng(300)
+    tours = np.stack([random_tour(n, rng) for _ in range(300)])
+    costs = np.array([O.succ_cost(xy, wt, t) for t in tours])
+    rc, s, o, st = inst.two_opt(tours, costs, mode=eng.BEST)
+    inst.close()
+    assert rc == 0
+    for b in range(0, 300, 7):
+        _, es, eo, est, _, _ = O.two_opt_best(xy, wt, tours[b])
+        assert (s[b] == es).all() and o[b] == eo and (st[b]["sweeps"], st[b]["evals"], st[b]["moves"]) == (est["sweeps"], est["evals"], est["moves"]), b
+
+
 @pytest.mark.parametrize("C", [2, 5, 16])
 @pytest.mark.parametrize("sorted_scan", [False, True])
 def test_cluster_random_tours_batches_and_ties(eng, ctx, monkeypatch, C, sorted_scan):
