@@ -417,7 +417,9 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         // batches on CLUSTER only with the sorted scan
         // (best-improvement batches: the cluster's sorted scan beats the GRID engine's lock-step launches about 2 x at every batch
         // size that fits the chip, one workgroup per tour included -- tools/best_batch.py)
-        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : C >= 8));
+        // (first-improvement batches the LDS engine cannot hold -- n > ~8000 -- go to the cluster at any size: 64 tours of
+        // rand10000 on 4 workgroups each 117 ms, GRID 240 ms -- tools/first_batch_big.py)
+        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (C >= 8 || !lds_ok)));
         if (force && *force == '1') { lds = false; cluster = false; }
         if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
         if (force && *force == '3' && C >= 1) cluster = true;
@@ -463,7 +465,7 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
 static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const bool want = engine == TSP_ENGINE_CLUSTER ||
-                          (tsp_cluster_fits(t, mode) && (t->B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : tsp_cluster_size(t, mode) >= 8)));
+                          (tsp_cluster_fits(t, mode) && (t->B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (tsp_cluster_size(t, mode) >= 8 || !tsp_lds_fits(t->inst)))));
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
             int fell = 0;
