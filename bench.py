@@ -63,10 +63,26 @@ def golden(name):
         return json.load(f)
 
 
-def sharded_configs(E, MS, ctx, rank, world, device):
+def sharded_configs(E, MS, ctx, rank, world, device, comm=None):
     """BASELINE configs[3] and [4] sharded k % world over the ranks: construct + 2-opt per rank, one all_reduce(MIN) of
-    the packed (cost, start), one broadcast of the winner's tour; every rank checks the winner against the goldens."""
+    the packed (cost, start), one broadcast of the winner's tour; every rank checks the winner against the goldens.
+    comm: the C ABI's RCCL communicator (engine.Comm) -- the two collectives then go through libtsp_hip.so
+    (tsp_dev_multistart_allreduce / _bcast_tour), as the C host's HEU_2opt_grasp_multistart runs them."""
     res = {}
+    how = ("none (1 GPU)" if world == 1 and comm is None else
+           "all_reduce(min) int64 + broadcast 4n bytes over RCCL, " +
+           ("through the C ABI (tsp_dev_multistart_allreduce / tsp_dev_multistart_bcast_tour)" if comm is not None
+            else "through torch.distributed"))
+
+    def per_rank(seconds):
+        if world == 1:
+            return [seconds]
+        import torch
+        import torch.distributed as dist
+        mine = torch.tensor([seconds], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(x.item()) for x in every]
 
     def wall(seconds):
         if world == 1:
@@ -87,7 +103,7 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     refine = MS.config4_refiner(E, inst, starts, stream)
     refine(MS.shard_starts(256, rank, world)[:4])   # warm
     t0 = time.perf_counter()
-    out = MS.run_sharded(refine, 256, n, rank, world, device)
+    out = MS.run_sharded(refine, 256, n, rank, world, device, comm=comm)
     t_all = wall(time.perf_counter() - t0)
     table = golden("oracle_vectors.json")["att532_multistart256"]
     # checks are recorded, never raised: a rank that threw between two collectives would leave the others waiting
@@ -95,9 +111,10 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     tour4 = fnv1a(out["tour"]) == table[122]["hash"]
     res["config4_att532_grasp256_2opt"] = {
         "starts": 256, "starts_per_rank": out["local_starts"], "wall_s": t_all, "refine_s_max_over_ranks": wall(out["seconds"]),
+        "refine_s_per_rank": per_rank(out["seconds"]),
         "best_true_cost": out["cost"], "best_start": out["start"], "reference_best": [28998, 122],
         "winner_is_the_reference_winner": bool(ok4), "winner_tour_matches_golden": bool(tour4),
-        "collectives": "all_reduce(MIN) int64 + broadcast 4n bytes" if world > 1 else "none (1 GPU)"}
+        "collectives": how}
     inst.close()
 
     # configs[4]: synthetic n = 5000, 128 random individuals (genetic.c:349-364, seed 123) each refined by alg_2opt
@@ -107,7 +124,7 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     perms = np.stack([rng.random_perm(5000) for _ in range(128)])
     refine = MS.config5_refiner(E, inst, perms)
     t0 = time.perf_counter()
-    out = MS.run_sharded(refine, 128, 5000, rank, world, device)
+    out = MS.run_sharded(refine, 128, 5000, rank, world, device, comm=comm)
     t_all = wall(time.perf_counter() - t0)
     gold = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]["individuals"]
     best = min(gold, key=lambda r: (r["cost"], r["k"]))
@@ -120,7 +137,8 @@ def sharded_configs(E, MS, ctx, rank, world, device):
     all5 = wall(0.0 if local5 else 1.0) == 0.0        # max over ranks of "some local individual differs"
     res["config5_rand5000_population128_2opt"] = {
         "individuals": 128, "individuals_per_rank": out["local_starts"], "wall_s": t_all,
-        "refine_s_max_over_ranks": wall(out["seconds"]), "best_cost": out["cost"], "best_individual": out["start"],
+        "refine_s_max_over_ranks": wall(out["seconds"]), "refine_s_per_rank": per_rank(out["seconds"]), "collectives": how,
+        "best_cost": out["cost"], "best_individual": out["start"],
         "golden_best": [int(best["cost"]), best["k"]], "rank0_reference_equivalent_evals": ev,
         "winner_is_the_golden_winner": bool(ok5), "winner_tour_matches_golden": bool(tour5),
         "every_individual_on_every_rank_matches_golden_counters": bool(all5)}
@@ -168,6 +186,107 @@ def cpu_baselines(xy, wt, succ0, obj0, cores):
     return out
 
 
+
+def launch_ranks(argv, n_ranks):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks (one process per GPU) ourselves.
+
+    The parent touches no GPU (no HIP call, no torch.cuda call -- it imports neither the engine nor torch) and never
+    exec()s: it starts N child processes of this very script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (what torch.distributed.run would set), relays rank 0's JSON line as its own last line of stdout and
+    exits non-zero if any child did.  The other ranks' stdout goes to stderr, prefixed."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as sk:                 # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               TSP_BENCH_CHILD="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n_ranks):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv,
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n_ranks)),
+                                      stdout=subprocess.PIPE, stderr=None, text=True))
+    lines = [[] for _ in procs]
+
+    def pump(r):
+        for ln in procs[r].stdout:
+            lines[r].append(ln.rstrip("\n"))
+            if r != 0:
+                sys.stderr.write("[rank %d] %s" % (r, ln))
+    threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    limit = float(os.environ.get("TSP_BENCH_LAUNCH_TIMEOUT", "3000"))
+    t0 = time.time()
+    codes = [None] * n_ranks
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        failed = any(c not in (None, 0) for c in codes)
+        if failed or time.time() - t0 > limit:
+            # a rank died (or the job hangs): the others would wait in a collective for ever -- end exactly the processes
+            # this parent started (by PID), give them a moment, then kill
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            if not failed:
+                codes = [c if c else 124 for c in codes]
+            break
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=10)
+    json_line = None
+    for ln in lines[0]:
+        if ln.startswith("{") and ln.endswith("}"):
+            json_line = ln
+        else:
+            sys.stderr.write("[rank 0] %s\n" % ln)
+    rc = next((c for c in codes if c), 0)
+    if json_line is None and rc == 0:
+        rc = 1
+    sys.stderr.flush()
+    if json_line is not None:
+        print(json_line, flush=True)
+    return rc
+
+
+def launcher_selftest_child():
+    """TSP_BENCH_SELFTEST=1 (CPU tests of the self-launcher, no GPU): every rank joins a gloo group, the ranks count
+    themselves with one all-reduce and run the multi-start launcher on the golden table; rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    from tsp_optimization_amd import multistart as MS
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    table = golden("oracle_vectors.json")["att532_multistart256"]
+
+    def refine(ids):
+        return [table[k]["opt_true"] for k in ids], np.stack([np.full(532, k, dtype=np.int32) for k in ids])
+    out = MS.run_sharded(refine, len(table), 532, rank, world)
+    fail_rank = os.environ.get("TSP_BENCH_SELFTEST_FAIL_RANK")
+    dist.barrier()
+    dist.destroy_process_group()
+    if fail_rank is not None and int(fail_rank) == rank:
+        sys.exit(3)
+    if rank == 0:
+        print("not the json line")
+        print(json.dumps({"selftest": True, "n_gpus": world, "ranks_seen": int(one.item()), "cost": out["cost"],
+                          "start": out["start"], "tour_ok": bool((out["tour"] == out["start"]).all())}), flush=True)
+    else:
+        print("rank %d done" % rank, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,13 +297,21 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the exhaustive sweeps (keeps a profile clean)")
     args = ap.parse_args()
 
+    # --gpus N without a launcher around this process: start the N ranks here, BEFORE anything touches the GPU
+    force_dist = os.environ.get("TSP_BENCH_FORCE_DIST") == "1"
+    selftest = os.environ.get("TSP_BENCH_SELFTEST") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist or selftest):
+        sys.exit(launch_ranks(sys.argv[1:], max(1, args.gpus)))
+    if selftest:
+        return launcher_selftest_child()
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     device = None
     # TSP_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (used to test it on a 1-GPU box)
-    if world > 1 or os.environ.get("TSP_BENCH_FORCE_DIST") == "1":
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -209,6 +336,27 @@ def main():
     xy = rand_instance(N_NODES)
     wt = E.EUC_2D
     ctx = E.Context(local_rank)
+    # The RCCL communicator of the C ABI (what the C host's HEU_2opt_grasp_multistart uses): rank 0's id travels to the
+    # other ranks as a byte tensor over the torch group.  A failure on rank 0 travels as an all-zero id, so that every
+    # rank takes the same branch and nobody waits in a collective the others never enter.
+    comm = None
+    dist_info = {}
+    if dist is not None:
+        import torch
+        idt = torch.zeros(E.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+        if rank == 0:
+            try:
+                idt.copy_(torch.frombuffer(bytearray(E.comm_unique_id()), dtype=torch.uint8))
+            except Exception as e:   # noqa: BLE001 -- reported in the line
+                dist_info["c_abi_comm_error"] = repr(e)
+        dist.broadcast(idt, src=0)
+        raw = idt.cpu().numpy().tobytes()
+        if any(raw):
+            comm = E.Comm(ctx, world, rank, raw)
+            dist_info["c_abi_comm"] = "tsp_dev_comm_init_rank over RCCL %d" % comm.rccl_version()
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)
+        dist_info["rccl_ranks_seen"] = int(one.item())
     inst = E.Instance(ctx, xy, wt, 1)
     start_node = rank % N_NODES
     succ0, obj0, status = inst.construct(E.GREEDY, np.array([start_node], dtype=np.int32))
@@ -254,6 +402,9 @@ def main():
     best_cost, best_rank = int(cost_now), rank
     if dist is not None:
         best_cost, best_rank = MS.allreduce_best(MS.pack(int(cost_now), rank), device=device)
+        if comm is not None:   # the same reduction through the C ABI's communicator: both must agree
+            c_cost, c_rank = MS.unpack(comm.allreduce_min(MS.pack(int(cost_now), rank)))
+            dist_info["c_abi_allreduce_agrees_with_torch"] = bool((c_cost, c_rank) == (best_cost, best_rank))
 
     out = {
         "metric": "2opt_edge_pair_evals_per_sec",
@@ -292,8 +443,10 @@ def main():
             "reference_equivalent_pairs_per_s": tot["evals"] * args.steps / elapsed,
         },
         "time_to_local_optimum_s": elapsed / args.steps,
-        "multistart_best": {"cost": best_cost, "rank": best_rank,
-                            "collective": "all_reduce(min) int64 over RCCL" if dist is not None else "none (1 GPU)"},
+        "multistart_best": dict({"cost": best_cost, "rank": best_rank,
+                                 "collective": ("all_reduce(min) int64 over RCCL (torch.distributed and the C ABI's "
+                                                "tsp_dev_multistart_allreduce)") if dist is not None else "none (1 GPU)"},
+                                **dist_info),
     }
 
     if rank == 0:
@@ -467,7 +620,7 @@ def main():
         guarded("alg_2opt_tabu_with_a_list", tabu_section)
 
     if not args.no_extras:
-        out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device)
+        out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device, comm)
         out["all_checks_ok"] = bool(out.get("parity", {}).get("final_tour_matches_golden", True) and
                                     all(v for d in out["other_configs"].values() for k, v in d.items()
                                         if k.startswith(("winner_", "every_"))))
@@ -489,6 +642,8 @@ def main():
 
     tours.close()
     inst.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -44,7 +44,8 @@ enum {
     TSP_DEV_E_HIP = -2,           /* a HIP call failed (tsp_dev_last_error() has the text) */
     TSP_DEV_E_ARG = -3,           /* bad argument (NULL, n < 4, unknown mode ...) */
     TSP_DEV_E_NOT_A_TOUR = -4,    /* a successor list is not one Hamiltonian cycle */
-    TSP_DEV_E_NOMEM = -5
+    TSP_DEV_E_NOMEM = -5,
+    TSP_DEV_E_COMM = -6           /* RCCL could not be opened or a collective failed (tsp_dev_comm_last_error()) */
 };
 
 /* 2-opt move selection */
@@ -74,6 +75,7 @@ typedef struct tsp_dev_ctx tsp_dev_ctx;     /* one device + stream */
 typedef struct tsp_dev_inst tsp_dev_inst;   /* node coordinates resident in HBM */
 typedef struct tsp_dev_tours tsp_dev_tours; /* B tours of one instance resident in HBM */
 typedef struct tsp_dev_tabu tsp_dev_tabu;   /* n(n-1)/2 tabu stamps resident in HBM */
+typedef struct tsp_dev_comm tsp_dev_comm;   /* one rank of an RCCL communicator (multi-start across GPUs) */
 
 typedef struct {
     int64_t sweeps;        /* completed passes over the (i<j) pair space                         */
@@ -228,6 +230,36 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
  * multi-start all-reduce(min) combines across ranks.  true_cost != 0 recomputes the cost from
  * the tour (GRASP's reported value carries an offset).  Written to *packed. */
 int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed);
+
+
+/* ---- multi-start across the GPUs of a node: generalises HEU_Grasp_iter's "keep the best start"
+ * (src/heuristics.c:510-544, :534-539) to starts sharded k % world over the ranks.  The path shards across tours only, so
+ * the whole exchange is ONE RCCL all-reduce(min) of the packed (cost << 24 | start id) and ONE broadcast of the winner's
+ * successor list (4n bytes) from the rank that owns it.  librccl is dlopen()ed by the first of these calls; errors of this
+ * group return TSP_DEV_E_COMM with the text in tsp_dev_comm_last_error(). ------------------------------------------------ */
+#define TSP_COMM_ID_BYTES 128
+const char *tsp_dev_comm_last_error(void);
+/* One process per GPU: rank 0 obtains the id (ncclGetUniqueId) and hands its TSP_COMM_ID_BYTES to every rank by a side
+ * channel of the caller's choice; then every rank calls init_rank with its own context (collective: returns when all have). */
+int tsp_dev_comm_unique_id(char *id);
+int tsp_dev_comm_init_rank(tsp_dev_ctx *ctx, int world, int rank, const char *id, tsp_dev_comm **out);
+/* One process, ndev devices (ncclCommInitAll): out[k] is rank k on ctxs[k]'s device; use the *_group calls below. */
+int tsp_dev_comm_init_all(tsp_dev_ctx *const *ctxs, int ndev, tsp_dev_comm **out);
+void tsp_dev_comm_destroy(tsp_dev_comm *comm);
+int tsp_dev_comm_info(const tsp_dev_comm *comm, int *rank, int *world, int *rccl_version);
+/* (cost, start id) -> the int64 whose minimum is (lowest cost, then lowest start id): cost << 24 | start_id.  Costs that
+ * are not non-negative integers below 2^39 (--fcost, GEO) cannot be packed: TSP_DEV_E_ARG, nothing is written. */
+int tsp_dev_multistart_pack(double cost, int start_id, int64_t *packed);
+/* all-reduce(min) of one int64 per rank over RCCL; every rank receives the minimum. */
+int tsp_dev_multistart_allreduce(tsp_dev_comm *comm, int64_t packed_local, int64_t *packed_best);
+/* broadcast of n ints (a successor list, `succ_stride` ints apart: 2 for &inst->solution.edges[0].j) from rank `root`. */
+int tsp_dev_multistart_bcast_tour(tsp_dev_comm *comm, int root, int *succ, int succ_stride, int n);
+/* The same two collectives for all ndev communicators of ONE process (ncclGroupStart / ncclGroupEnd around them).
+ * packed_local[k] / packed_best[k] belong to rank k; the tour travels from rank `root`'s device to every device and is
+ * read back from `read_back_rank`'s (so that a caller can check what a non-root rank received). */
+int tsp_dev_multistart_allreduce_group(tsp_dev_comm *const *comms, int ndev, const int64_t *packed_local, int64_t *packed_best);
+int tsp_dev_multistart_bcast_tour_group(tsp_dev_comm *const *comms, int ndev, int root, const int *succ_root, int succ_stride,
+                                        int n, int read_back_rank, int *succ_out);
 
 #ifdef __cplusplus
 }

@@ -44,7 +44,8 @@ typedef enum {                                                                  
     SOLVE_UCUT, SOLVE_HARD_FIXING, SOLVE_HARD_FIXING2, SOLVE_SOFT_FIXING,
     SOLVE_GREEDY, SOLVE_GREEDY_ITER, SOLVE_EXTR_MIL, SOLVE_GRASP, SOLVE_GRASP_ITER,
     SOLVE_2OPT_GRASP, SOLVE_2OPT_GRASP_ITER, SOLVE_2OPT_GREEDY, SOLVE_2OPT_GREEDY_ITER, SOLVE_2OPT_EXTR_MIL,
-    SOLVE_VNS, SOLVE_TABU_STEP, SOLVE_TABU_LIN, SOLVE_TABU_RAND, SOLVE_GENETIC
+    SOLVE_VNS, SOLVE_TABU_STEP, SOLVE_TABU_LIN, SOLVE_TABU_RAND, SOLVE_GENETIC,
+    SOLVE_2OPT_GRASP_MULTI   /* extension of this build (after the reference's last value): BASELINE configs[3] */
 } solver_type;
 
 typedef enum { UDIR_EDGE, DIR_EDGE } edge_type;                                          /* :99-102 */
@@ -140,6 +141,12 @@ void export_tour(instance *inst);
  * inst->solution (ties -> lowest start).  rank/world shard the starts (k % world == rank). */
 int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost,
                               int *best_start);
+/* world > 1 (one process per GPU, device LOCAL_RANK): the ranks agree on the winner with one RCCL all-reduce(min) of
+ * (true cost << 24 | start) and one broadcast of its tour (tsp_dev_multistart_* of include/tsp_hip.h); the RCCL id travels
+ * from rank 0 through the file TSP_RCCL_ID_FILE.  The same job in ONE process on devices 0 .. gpus-1 (one thread per GPU,
+ * ncclCommInitAll, grouped collectives); shard_seconds[gpus] (may be NULL) receives every GPU's construct + 2-opt time. */
+int tsp_host_multistart_gpus(instance *inst, int starts, int gpus, double *best_true_cost, int *best_start,
+                             double *shard_seconds);
 /* The two drivers with a cap on the number of rounds / iterations in addition to the time limit
  * (max < 0 = time limit only, which is what HEU_VNS / HEU_Tabu_* pass).  policy: 0 step, 1 linear,
  * 2 random.  The reference's loops are bounded by the wall clock alone, which no test can reproduce. */

@@ -87,6 +87,18 @@ def lib():
         L.tsp_dev_tours_restore.argtypes = [vp]
         L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+        L.tsp_dev_comm_last_error.restype = C.c_char_p
+        L.tsp_dev_comm_unique_id.argtypes = [C.c_char_p]
+        L.tsp_dev_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+        L.tsp_dev_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.tsp_dev_comm_destroy.argtypes = [vp]
+        L.tsp_dev_comm_destroy.restype = None
+        L.tsp_dev_comm_info.argtypes = [vp, ip, ip, ip]
+        L.tsp_dev_multistart_pack.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_int64)]
+        L.tsp_dev_multistart_allreduce.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.tsp_dev_multistart_bcast_tour.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int]
+        L.tsp_dev_multistart_allreduce_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.tsp_dev_multistart_bcast_tour_group.argtypes = [C.POINTER(vp), C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, ip]
         _lib = L
     return _lib
 
@@ -101,13 +113,21 @@ EXPORTED = [
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
     "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
+    "tsp_dev_comm_last_error", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
+    "tsp_dev_comm_info", "tsp_dev_multistart_pack", "tsp_dev_multistart_allreduce", "tsp_dev_multistart_bcast_tour",
+    "tsp_dev_multistart_allreduce_group", "tsp_dev_multistart_bcast_tour_group",
 ]
+
+COMM_ID_BYTES = 128
+E_COMM = -6
 
 
 def _check(rc, allow=(OK,)):
     if rc in allow:
         return rc
     msg = lib().tsp_dev_last_error().decode()
+    if rc == E_COMM:
+        msg = lib().tsp_dev_comm_last_error().decode() + " " + msg
     raise TspDeviceError("tsp_dev call failed with %d %s" % (rc, msg))
 
 
@@ -392,3 +412,50 @@ class Tours:
         p = C.c_int64(0)
         _check(lib().tsp_dev_tours_best(self._h, 1 if true_cost else 0, C.byref(p)))
         return p.value >> 24, p.value & 0xFFFFFF, p.value
+
+
+def multistart_pack(cost, start_id):
+    """(cost, start id) -> cost << 24 | start id through the C ABI; raises ValueError for costs the all-reduce cannot carry
+    (not a non-negative integer below 2^39: --fcost, GEO)."""
+    p = C.c_int64(0)
+    if lib().tsp_dev_multistart_pack(float(cost), int(start_id), C.byref(p)) != OK:
+        raise ValueError("cost %r / start %r cannot be packed for the all-reduce(min)" % (cost, start_id))
+    return p.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0): 128 bytes to hand to every rank."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().tsp_dev_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """One rank of the RCCL communicator the C ABI's multi-start epilogue runs on (tsp_dev_comm_init_rank)."""
+
+    def __init__(self, ctx, world, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.ctx, self.world, self.rank = ctx, world, rank
+        self._h = C.c_void_p()
+        _check(lib().tsp_dev_comm_init_rank(ctx._h, world, rank, unique_id, C.byref(self._h)))
+
+    def rccl_version(self):
+        v = C.c_int(0)
+        _check(lib().tsp_dev_comm_info(self._h, None, None, C.byref(v)))
+        return v.value
+
+    def allreduce_min(self, packed):
+        out = C.c_int64(0)
+        _check(lib().tsp_dev_multistart_allreduce(self._h, int(packed), C.byref(out)))
+        return out.value
+
+    def bcast_tour(self, root, succ):
+        """succ: int32 [n], the winner's tour on `root`, overwritten with it on the other ranks."""
+        assert succ.dtype == np.int32 and succ.flags["C_CONTIGUOUS"]
+        _check(lib().tsp_dev_multistart_bcast_tour(self._h, root, _i(succ), 1, len(succ)))
+        return succ
+
+    def close(self):
+        if self._h:
+            lib().tsp_dev_comm_destroy(self._h)
+            self._h = C.c_void_p()

@@ -15,8 +15,9 @@
 #include <pthread.h>
 #include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
-#include "../../include/tsp_hip.h"
+#include "tsp_hip.h"
 
 #define GRASP_ITER_TIME_LIM 120 /* src/heuristics.c:11 */
 #define MULTISTART_BATCH 256    /* GRASP starts constructed per device call in HEU_Grasp_iter */
@@ -34,6 +35,9 @@ typedef struct {
 #define CACHE_SLOTS 8
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static tsp_dev_ctx *g_ctx = NULL;
+static tsp_dev_comm *g_comm = NULL;   /* one process per GPU: this process's rank of the RCCL communicator */
+/* CLI extensions of this build (-starts, -gpus): instance_params is the reference's struct and takes no new fields */
+static int g_cli_starts = 256, g_cli_gpus = 0;
 static cache_slot g_cache[CACHE_SLOTS];
 /* device copy of the skip_edge array a caller keeps passing to alg_2opt_tabu (see there) */
 static struct { int *host; tsp_dev_inst *dev; tsp_dev_tabu *tb; size_t bytes; int registered; } g_tabu_cache;
@@ -56,6 +60,7 @@ static void dev_fail(const char *what, int rc) {
 static tsp_dev_ctx *ctx_locked(void) {
     if (!g_ctx) {
         const char *d = getenv("TSP_DEVICE");
+        if (!d || !*d) d = getenv("LOCAL_RANK");   /* one process per GPU under torchrun / mpirun style launchers */
         int rc = tsp_dev_open(d ? atoi(d) : 0, &g_ctx);
         if (rc) dev_fail("tsp_dev_open", rc);
         atexit(tsp_host_shutdown);
@@ -99,6 +104,7 @@ static tsp_dev_inst *dev_inst_locked(instance *inst) {
 void tsp_host_shutdown(void) {
     pthread_mutex_lock(&g_lock);
     tabu_cache_drop();
+    if (g_comm) { tsp_dev_comm_destroy(g_comm); g_comm = NULL; }
     for (int k = 0; k < CACHE_SLOTS; k++)
         if (g_cache[k].dev) { tsp_dev_inst_destroy(g_cache[k].dev); memset(&g_cache[k], 0, sizeof g_cache[k]); }
     if (g_ctx) { tsp_dev_close(g_ctx); g_ctx = NULL; }
@@ -735,15 +741,19 @@ int fitness_batch(instance *inst, const int *chromosomes, int count, double *fit
     return rc;
 }
 
-/* BASELINE config 4: S GRASP starts (stream order of heuristics.c:519,:127), alg_2opt on each, best true cost */
-int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
-    const int n = inst->num_nodes;
-    if (starts < 1 || world < 1 || rank < 0 || rank >= world) return -1;
+/* ---- multi-start across GPUs ----------------------------------------------------------------------
+ * Generalises HEU_Grasp_iter's loop (heuristics.c:510-544: random start :519, grasp(), keep the strictly better one :534):
+ * every start is refined by alg_2opt, start k runs on rank k % world, and the ranks agree on the winner with ONE RCCL
+ * all-reduce(min) of (true cost << 24 | k) and ONE broadcast of its successor list (tsp_dev_multistart_* of the C ABI). */
+
+/* the libc stream of `starts` GRASP starts in the reference's draw order; keeps the draws of the starts k % world == rank */
+static int draw_shard(int n, int starts, int rank, int world, int **node_out, int **gid_out, double **u_out) {
     int mine = 0;
     for (int k = 0; k < starts; k++) mine += (k % world == rank);
     int *node = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
     int *gid = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
     double *u = malloc(sizeof(double) * (size_t)(mine ? mine : 1) * n);
+    if (!node || !gid || !u) LOG_E("multistart: out of memory");
     int m = 0;
     for (int k = 0; k < starts; k++) { /* every rank walks the whole stream so that start k is the same everywhere */
         const int nd = (int)(URAND() * (n - 1));
@@ -755,38 +765,215 @@ int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, d
             for (int q = 0; q < n; q++) (void)random();
         }
     }
-    int *succ = malloc(sizeof(int) * (size_t)(mine ? mine : 1) * n);
-    double *obj = malloc(sizeof(double) * (size_t)(mine ? mine : 1));
-    double *truec = malloc(sizeof(double) * (size_t)(mine ? mine : 1));
+    *node_out = node; *gid_out = gid; *u_out = u;
+    return mine;
+}
+
+/* GRASP + alg_2opt + true cost for one shard on one device instance; best (cost, global start id, tour) of the shard */
+static int refine_shard(tsp_dev_inst *d, int n, int mine, const int *node, const int *gid, const double *u, double limit,
+                        double *best_cost, int *best_k, int *best_succ) {
+    *best_cost = DBL_MAX; *best_k = -1;
+    if (mine <= 0) return 0;
+    int *succ = malloc(sizeof(int) * (size_t)mine * n);
+    int *perm = malloc(sizeof(int) * (size_t)mine * n);
+    double *obj = malloc(sizeof(double) * (size_t)mine), *truec = malloc(sizeof(double) * (size_t)mine);
+    if (!succ || !perm || !obj || !truec) LOG_E("multistart: out of memory");
+    int rc = tsp_dev_construct(d, TSP_CONSTRUCT_GRASP, mine, node, u, succ, 1, n, obj, NULL);
+    if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, obj, limit, NULL);
+    if (rc >= 0) {  /* true cost = fitness of the tour walked from node 0 (the reported obj carries GRASP's offset) */
+        for (int b = 0; b < mine; b++) { int v = 0; for (int q = 0; q < n; q++) { perm[(size_t)b * n + q] = v; v = succ[(size_t)b * n + v]; } }
+        int rc2 = tsp_dev_perm_cost(d, mine, perm, n, truec);
+        if (rc2) rc = rc2;
+    }
+    if (rc >= 0) {
+        int bm = 0;
+        for (int b = 0; b < mine; b++)
+            if (truec[b] < *best_cost) { *best_cost = truec[b]; *best_k = gid[b]; bm = b; }
+        memcpy(best_succ, succ + (size_t)bm * n, sizeof(int) * (size_t)n);
+    }
+    free(succ); free(perm); free(obj); free(truec);
+    return rc;
+}
+
+#define NO_RESULT_PACKED ((int64_t)1 << 62)
+
+/* One process per GPU: the communicator of this process, formed on first use from RANK / WORLD_SIZE.  Rank 0 obtains the
+ * RCCL id and leaves it in a file (TSP_RCCL_ID_FILE, default /tmp/tsp_rccl_id.<launcher pid>.<MASTER_PORT>), the others
+ * wait for it; the file is removed once every rank is in. */
+static tsp_dev_comm *comm_locked(int rank, int world) {
+    if (g_comm) return g_comm;
+    char path[512];
+    const char *f = getenv("TSP_RCCL_ID_FILE"), *port = getenv("MASTER_PORT");
+    if (f && *f) snprintf(path, sizeof path, "%s", f);
+    else snprintf(path, sizeof path, "/tmp/tsp_rccl_id.%ld.%s", (long)getppid(), port && *port ? port : "0");
+    char id[TSP_COMM_ID_BYTES];
+    if (rank == 0) {
+        int rc = tsp_dev_comm_unique_id(id);
+        if (rc) LOG_E("tsp_dev_comm_unique_id failed with %d %s", rc, tsp_dev_comm_last_error());
+        char tmp[600];
+        snprintf(tmp, sizeof tmp, "%s.tmp", path);
+        FILE *fp = fopen(tmp, "wb");
+        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id) LOG_E("cannot write the RCCL id to %s", tmp);
+        fclose(fp);
+        if (rename(tmp, path)) LOG_E("cannot publish the RCCL id as %s", path);
+    } else {
+        struct timeval t0, t1;
+        gettimeofday(&t0, 0);
+        for (;;) {
+            FILE *fp = fopen(path, "rb");
+            if (fp) {
+                const size_t got = fread(id, 1, sizeof id, fp);
+                fclose(fp);
+                if (got == sizeof id) break;
+            }
+            gettimeofday(&t1, 0);
+            if (get_elapsed_time(t0, t1) > 120.0) LOG_E("rank %d: no RCCL id in %s after 120 s (is rank 0 running?)", rank, path);
+            struct timespec ts = {0, 20 * 1000 * 1000};
+            nanosleep(&ts, NULL);
+        }
+    }
+    int rc = tsp_dev_comm_init_rank(ctx_locked(), world, rank, id, &g_comm);
+    if (rc) LOG_E("tsp_dev_comm_init_rank failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    if (rank == 0) (void)remove(path);   /* init_rank is collective: every rank has read it */
+    return g_comm;
+}
+
+/* BASELINE config 4: `starts` GRASP starts (stream order of heuristics.c:519, :127), alg_2opt on each, best TRUE cost.
+ * world == 1: this process refines every start.  world > 1 (one process per GPU): this rank refines the starts
+ * k % world == rank on its device, then the ranks run the all-reduce(min) + broadcast over RCCL, so that EVERY rank
+ * returns the global winner in inst->solution, *best_true_cost and *best_start. */
+int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+    const int n = inst->num_nodes;
+    if (starts < 1 || world < 1 || rank < 0 || rank >= world) return -1;
+    int *node, *gid;
+    double *u;
+    const int mine = draw_shard(n, starts, rank, world, &node, &gid, &u);
+    int *best_succ = malloc(sizeof(int) * (size_t)n);
     double best = DBL_MAX;
-    int best_k = -1, best_m = -1;
-    if (mine > 0) {
+    int best_k = -1;
+    pthread_mutex_lock(&g_lock);
+    int rc = refine_shard(dev_inst_locked(inst), n, mine, node, gid, u, limit_of(inst), &best, &best_k, best_succ);
+    pthread_mutex_unlock(&g_lock);
+    if (rc < 0) dev_fail("multistart", rc);
+    const char *force = getenv("TSP_FORCE_COMM");   /* tests: run the collectives with a single rank too */
+    if (world > 1 || (force && *force == '1')) {
+        int64_t mine_packed = NO_RESULT_PACKED, win = 0;
+        if (best_k >= 0 && tsp_dev_multistart_pack(best, best_k, &mine_packed))
+            LOG_E("multi-GPU multi-start needs integer costs (the all-reduce packs cost << 24 | start): got %f", best);
         pthread_mutex_lock(&g_lock);
-        tsp_dev_inst *d = dev_inst_locked(inst);
-        int rc = tsp_dev_construct(d, TSP_CONSTRUCT_GRASP, mine, node, u, succ, 1, n, obj, NULL);
-        if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, obj, limit_of(inst), NULL);
-        if (rc >= 0) {  /* true cost = fitness of the tour walked from node 0 (the reported obj carries GRASP's offset) */
-            int *perm = malloc(sizeof(int) * (size_t)mine * n);
-            for (int b = 0; b < mine; b++) { int v = 0; for (int q = 0; q < n; q++) { perm[(size_t)b * n + q] = v; v = succ[(size_t)b * n + v]; } }
-            int rc2 = tsp_dev_perm_cost(d, mine, perm, n, truec);
-            if (rc2) rc = rc2;
-            free(perm);
+        tsp_dev_comm *cm = comm_locked(rank, world);
+        rc = tsp_dev_multistart_allreduce(cm, mine_packed, &win);
+        if (!rc && win != NO_RESULT_PACKED) {
+            best = (double)(win >> 24); best_k = (int)(win & 0xffffff);
+            rc = tsp_dev_multistart_bcast_tour(cm, best_k % world, best_succ, 1, n);
         }
         pthread_mutex_unlock(&g_lock);
-        if (rc < 0) dev_fail("multistart", rc);
-        for (int b = 0; b < mine; b++)
-            if (truec[b] < best) { best = truec[b]; best_k = gid[b]; best_m = b; }
-        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = succ[(size_t)best_m * n + v]; }
+        if (rc) LOG_E("multi-start collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    }
+    if (best_k >= 0) {
+        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = best_succ[v]; }
         inst->solution.obj_best = best;
     }
     if (best_true_cost) *best_true_cost = best;
     if (best_start) *best_start = best_k;
-    free(node); free(gid); free(u); free(succ); free(obj); free(truec);
+    free(node); free(gid); free(u); free(best_succ);
+    return 0;
+}
+
+/* The same job in ONE process on `gpus` devices (0 .. gpus-1): one thread, context and device instance per GPU, shard
+ * k % gpus on GPU k, then ncclCommInitAll + the grouped all-reduce(min) + broadcast.  The libc stream is drawn once,
+ * up front, by the calling thread (random() is process-global, heuristics.c:519). */
+typedef struct {
+    instance *inst; int dev, mine; const int *node, *gid; const double *u; double limit;
+    tsp_dev_ctx *ctx; tsp_dev_inst *dinst; double best; int best_k; int *best_succ; int rc; double seconds;
+} gpu_job;
+
+static void *gpu_job_run(void *arg) {
+    gpu_job *j = arg;
+    struct timeval t0, t1;
+    gettimeofday(&t0, 0);
+    const int n = j->inst->num_nodes;
+    j->rc = tsp_dev_open(j->dev, &j->ctx);
+    if (!j->rc) j->rc = tsp_dev_inst_create(j->ctx, (const double *)j->inst->nodes, n, (int)j->inst->weight_type,
+                                            j->inst->params.integer_cost ? 1 : 0, &j->dinst);
+    if (!j->rc) j->rc = refine_shard(j->dinst, n, j->mine, j->node, j->gid, j->u, j->limit, &j->best, &j->best_k, j->best_succ);
+    gettimeofday(&t1, 0);
+    j->seconds = get_elapsed_time(t0, t1);
+    return NULL;
+}
+
+int tsp_host_multistart_gpus(instance *inst, int starts, int gpus, double *best_true_cost, int *best_start, double *shard_seconds) {
+    const int n = inst->num_nodes;
+    if (starts < 1 || gpus < 1 || gpus > 64) return -1;
+    if (tsp_dev_count() < gpus) LOG_E("tsp_host_multistart_gpus: %d GPUs asked for, %d visible", gpus, tsp_dev_count());
+    gpu_job *jobs = calloc((size_t)gpus, sizeof(gpu_job));
+    int **nodes = calloc((size_t)gpus, sizeof(int *)), **gids = calloc((size_t)gpus, sizeof(int *));
+    double **us = calloc((size_t)gpus, sizeof(double *));
+    /* one pass over the stream per GPU would draw it `gpus` times: draw once, deal the starts out */
+    for (int g = 0; g < gpus; g++) {
+        int mine = 0;
+        for (int k = 0; k < starts; k++) mine += (k % gpus == g);
+        nodes[g] = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
+        gids[g] = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
+        us[g] = malloc(sizeof(double) * (size_t)(mine ? mine : 1) * n);
+        jobs[g].mine = 0;
+    }
+    for (int k = 0; k < starts; k++) {
+        const int g = k % gpus, m = jobs[g].mine++;
+        nodes[g][m] = (int)(URAND() * (n - 1)); gids[g][m] = k;
+        for (int q = 0; q < n; q++) us[g][(size_t)m * n + q] = URAND();
+    }
+    pthread_t *th = calloc((size_t)gpus, sizeof(pthread_t));
+    for (int g = 0; g < gpus; g++) {
+        jobs[g].inst = inst; jobs[g].dev = g; jobs[g].node = nodes[g]; jobs[g].gid = gids[g]; jobs[g].u = us[g];
+        jobs[g].limit = limit_of(inst); jobs[g].best_succ = malloc(sizeof(int) * (size_t)n);
+        if (pthread_create(&th[g], NULL, gpu_job_run, &jobs[g])) LOG_E("pthread_create failed");
+    }
+    for (int g = 0; g < gpus; g++) pthread_join(th[g], NULL);
+    for (int g = 0; g < gpus; g++)
+        if (jobs[g].rc < 0) dev_fail("tsp_host_multistart_gpus: shard", jobs[g].rc);
+    /* the epilogue: all-reduce(min) of the packed bests, broadcast of the winner's tour from its owner, over RCCL */
+    tsp_dev_ctx **ctxs = calloc((size_t)gpus, sizeof(tsp_dev_ctx *));
+    tsp_dev_comm **comms = calloc((size_t)gpus, sizeof(tsp_dev_comm *));
+    int64_t *loc = calloc((size_t)gpus, sizeof(int64_t)), *win = calloc((size_t)gpus, sizeof(int64_t));
+    for (int g = 0; g < gpus; g++) {
+        ctxs[g] = jobs[g].ctx;
+        loc[g] = NO_RESULT_PACKED;
+        if (jobs[g].best_k >= 0 && tsp_dev_multistart_pack(jobs[g].best, jobs[g].best_k, &loc[g]))
+            LOG_E("multi-GPU multi-start needs integer costs (the all-reduce packs cost << 24 | start): got %f", jobs[g].best);
+    }
+    int rc = tsp_dev_comm_init_all(ctxs, gpus, comms);
+    if (!rc) rc = tsp_dev_multistart_allreduce_group(comms, gpus, loc, win);
+    for (int g = 1; g < gpus && !rc; g++) if (win[g] != win[0]) rc = TSP_DEV_E_COMM;   /* every rank must hold the same minimum */
+    double best = DBL_MAX;
+    int best_k = -1;
+    if (!rc && win[0] != NO_RESULT_PACKED) {
+        best = (double)(win[0] >> 24); best_k = (int)(win[0] & 0xffffff);
+        const int owner = best_k % gpus;
+        int *tour = malloc(sizeof(int) * (size_t)n);
+        rc = tsp_dev_multistart_bcast_tour_group(comms, gpus, owner, jobs[owner].best_succ, 1, n, (owner + 1) % gpus, tour);
+        if (!rc) for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = tour[v]; }
+        free(tour);
+        inst->solution.obj_best = best;
+    }
+    if (rc) LOG_E("multi-start collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    if (best_true_cost) *best_true_cost = best;
+    if (best_start) *best_start = best_k;
+    for (int g = 0; g < gpus; g++) {
+        if (shard_seconds) shard_seconds[g] = jobs[g].seconds;
+        tsp_dev_comm_destroy(comms[g]);
+        if (jobs[g].dinst) tsp_dev_inst_destroy(jobs[g].dinst);
+        if (jobs[g].ctx) tsp_dev_close(jobs[g].ctx);
+        free(nodes[g]); free(gids[g]); free(us[g]); free(jobs[g].best_succ);
+    }
+    free(jobs); free(nodes); free(gids); free(us); free(th); free(ctxs); free(comms); free(loc); free(win);
     return 0;
 }
 
 /* ---- src/solver.c:262-299 ------------------------------------------------------------------------------- */
 int TSP_heuc(instance *inst) {
+    const char *ws = getenv("WORLD_SIZE"), *rk = getenv("RANK");
+    const int world_env = ws && atoi(ws) > 1 && rk ? atoi(ws) : 1, rank_env = world_env > 1 ? atoi(rk) : 0;
     if (inst->params.seed >= 0) srandom((unsigned)inst->params.seed);
     inst->num_columns = (long)inst->num_nodes * (inst->num_nodes - 1) / 2;
     inst->solution.edges = calloc((size_t)inst->num_nodes, sizeof(edge));
@@ -805,6 +992,15 @@ int TSP_heuc(instance *inst) {
     case SOLVE_2OPT_EXTR_MIL: HEU_2opt_extramileage(inst); break;
     case SOLVE_VNS: HEU_VNS(inst); break;
     case SOLVE_GENETIC: HEU_Genetic(inst); break;
+    case SOLVE_2OPT_GRASP_MULTI: {
+        /* one process, -gpus G devices: threads + ncclCommInitAll; one process per GPU (RANK / WORLD_SIZE in the
+         * environment, as torchrun / mpirun set them): ncclCommInitRank, device LOCAL_RANK; else this process alone */
+        double cost = 0.0; int start = -1;
+        if (g_cli_gpus >= 1 && world_env == 1) tsp_host_multistart_gpus(inst, g_cli_starts, g_cli_gpus, &cost, &start, NULL);
+        else HEU_2opt_grasp_multistart(inst, g_cli_starts, rank_env, world_env, &cost, &start);
+        if (inst->params.verbose >= 1 && !inst->params.perf_prof && rank_env == 0) LOG_I("best start %d of %d, true cost %0.0f", start, g_cli_starts, cost);
+        break;
+    }
     case SOLVE_TABU_STEP:
     case SOLVE_TABU_LIN:
     case SOLVE_TABU_RAND:
@@ -813,12 +1009,13 @@ int TSP_heuc(instance *inst) {
         break;
     default:
         LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, EXTR_MILE, GRASP, GRASP_ITER, 2OPT_EXTR_MIL, "
-              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND, GENETIC)",
+              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GRASP_MULTI, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND, GENETIC)",
               inst->params.method.name ? inst->params.method.name : "?");
     }
     gettimeofday(&t1, 0);
     const double elapsed = get_elapsed_time(t0, t1);
     inst->solution.time_to_solve = elapsed;
+    if (rank_env != 0) return 0;   /* one process per GPU: every rank holds the winner, rank 0 reports it */
     export_tour(inst);
     if (inst->params.perf_prof) printf("%0.2f", inst->solution.obj_best);          /* solver.c:291-292 */
     else printf("\n\n\nTIME TO SOLVE %0.6fs\n\n\n", elapsed);                       /* solver.c:295 */
@@ -837,6 +1034,7 @@ static const struct { const char *prefix; int len; solver_type id; const char *n
     {"GRASP_ITER", 10, SOLVE_GRASP_ITER, "GRASP ITERATIVE HEURISTIC"},
     {"2OPT_GRASP", 9, SOLVE_2OPT_GRASP, "2-OPT HEURISTIC WITH GRASP INITIALIZATION"},
     {"2OPT_GRASP_ITER", 15, SOLVE_2OPT_GRASP_ITER, "2-OPT HEURISTIC WITH ITERATIVE GRASP INITIALIZATION"},
+    {"2OPT_GRASP_MULTI", 16, SOLVE_2OPT_GRASP_MULTI, "GRASP MULTI-START, 2-OPT ON EVERY START, SHARDED OVER THE GPUS (extension)"},
     {"2OPT_GREEDY", 11, SOLVE_2OPT_GREEDY, "2-OPT HEURISTIC WITH GREEDY INITIALIZATION"},
     {"2OPT_GREEDY_ITER", 16, SOLVE_2OPT_GREEDY_ITER, "2-OPT HEURISTIC WITH ITERATIVE GREEDY INITIALIZATION"},
     {"2OPT_EXTR_MIL", 13, SOLVE_2OPT_EXTR_MIL, "2-OPT HEURISTIC WITH EXTRA MILEAGE INITIALIZATION"},
@@ -873,6 +1071,8 @@ void parse_comand_line(int argc, const char *argv[], instance *inst) { /* src/ut
         if (!strcmp(a, "-threads")) { if (!has_value) { need_help = 1; continue; } inst->params.num_threads = atoi(argv[++i]); continue; }
         if (!strcmp(a, "-verbose")) { if (!has_value) { need_help = 1; continue; } inst->params.verbose = atoi(argv[++i]); continue; }
         if (!strcmp(a, "-seed")) { if (!has_value) { need_help = 1; continue; } inst->params.seed = atoi(argv[++i]); continue; }
+        if (!strcmp(a, "-starts")) { if (!has_value) { need_help = 1; continue; } g_cli_starts = atoi(argv[++i]); continue; }   /* extension */
+        if (!strcmp(a, "-gpus")) { if (!has_value) { need_help = 1; continue; } g_cli_gpus = atoi(argv[++i]); continue; }       /* extension */
         if (!strcmp(a, "-method")) {
             if (!has_value) { need_help = 1; continue; }
             const char *m = argv[++i];
@@ -904,6 +1104,8 @@ void parse_comand_line(int argc, const char *argv[], instance *inst) { /* src/ut
         printf("-verbose <level>          The verbosity level of the debugging printing\n");
         printf("-method <type>            The method used to solve the problem. Use \"--methods\" to see the list of available methods\n");
         printf("-seed <seed>              The seed for random generation\n");
+        printf("-starts <S>               2OPT_GRASP_MULTI: number of GRASP starts (default 256)\n");
+        printf("-gpus <G>                 2OPT_GRASP_MULTI: GPUs of this process (or launch one process per GPU with RANK / WORLD_SIZE set)\n");
         printf("--fcost                   Whether you want float costs in the problem\n");
         printf("--perfprof                Print only the objective (machine mode)\n");
         printf("--v, --version            Software's current version\n");

@@ -28,11 +28,29 @@ def owner_of(start_id, world):
     return start_id % world
 
 
+class UnpackableCost(ValueError):
+    """The all-reduce(min) carries (cost << 24 | start id): only non-negative integer costs below 2^39 fit (the reference's
+    default integer_cost = 1; not --fcost, not GEO's tolerance tier)."""
+
+
 def pack(cost, start_id):
-    c = int(cost)
-    assert c == cost and c >= 0, "packed reduction needs non-negative integer costs"
-    assert 0 <= start_id <= ID_MASK
+    """Same rule as tsp_dev_multistart_pack of the C ABI.  Raises UnpackableCost -- callers that sit between two
+    collectives use try_pack and agree on the failure through the reduction itself."""
+    ok = cost == cost and 0 <= cost < float(1 << 39)      # not NaN, in range (before int(): int(nan) raises)
+    c = int(cost) if ok else -1
+    if not (ok and c == cost and 0 <= start_id <= ID_MASK):
+        raise UnpackableCost("cost %r / start %r" % (cost, start_id))
     return (c << ID_BITS) | start_id
+
+
+PACK_ERROR = -1      # smaller than every packed value: a rank that could not pack wins the MIN and every rank sees it
+
+
+def try_pack(cost, start_id):
+    try:
+        return pack(cost, start_id)
+    except UnpackableCost:
+        return PACK_ERROR
 
 
 def unpack(packed):
@@ -43,10 +61,10 @@ NO_RESULT = (1 << 62)
 
 
 def local_best(costs, start_ids):
-    """Packed minimum over this rank's starts (NO_RESULT for an empty shard)."""
+    """Packed minimum over this rank's starts (NO_RESULT for an empty shard; PACK_ERROR if a cost cannot be packed)."""
     best = NO_RESULT
     for c, k in zip(costs, start_ids):
-        best = min(best, pack(c, k))
+        best = min(best, try_pack(c, k))
     return best
 
 
@@ -66,8 +84,11 @@ def broadcast_winner(succ, winner_start, world, device=None):
     return succ
 
 
-def run_sharded(refine, num_starts, n, rank=0, world=1, device=None):
+def run_sharded(refine, num_starts, n, rank=0, world=1, device=None, comm=None):
     """The multi-start launcher.
+
+    comm: an engine.Comm (the C ABI's RCCL communicator, tsp_dev_multistart_allreduce / _bcast_tour) -- the collectives then
+    run through libtsp_hip.so exactly as the C host's HEU_2opt_grasp_multistart runs them; None: torch.distributed.
 
     refine(ids) -> (costs, tours): for the global start ids `ids` (this rank's shard, ascending) the true tour cost of
     every refined start and the refined tours as an int32 array [len(ids), n] of successor lists.
@@ -81,15 +102,31 @@ def run_sharded(refine, num_starts, n, rank=0, world=1, device=None):
     seconds = time.perf_counter() - t0
     tours = np.ascontiguousarray(tours, dtype=np.int32).reshape(len(ids), n)
     packed = local_best(costs, ids)
-    if world > 1:
+    if comm is not None:
+        win = comm.allreduce_min(packed)
+        if win == PACK_ERROR:
+            raise UnpackableCost("a rank holds a cost the packed all-reduce cannot carry")   # every rank raises: no one waits
+        cost, start = unpack(win)
+        tour = np.zeros(n, dtype=np.int32)
+        if owner_of(start, world) == rank:
+            tour[:] = tours[ids.index(start)]
+        comm.bcast_tour(owner_of(start, world), tour)
+    elif world > 1:
         import torch
-        cost, start = allreduce_best(packed, device=device)
+        t = torch.tensor([packed], dtype=torch.int64, device=device)
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == PACK_ERROR:
+            raise UnpackableCost("a rank holds a cost the packed all-reduce cannot carry")   # every rank raises: no one waits
+        cost, start = unpack(int(t.item()))
         buf = torch.zeros(n, dtype=torch.int32, device=device)
         if owner_of(start, world) == rank:
             buf.copy_(torch.from_numpy(tours[ids.index(start)]))
         broadcast_winner(buf, start, world)
         tour = buf.cpu().numpy()
     else:
+        if packed == PACK_ERROR:
+            raise UnpackableCost("a cost the packed reduction cannot carry")
         assert packed != NO_RESULT
         cost, start = unpack(packed)
         tour = tours[ids.index(start)].copy()
@@ -174,6 +211,8 @@ def config4_refiner(E, inst, starts, stream):
         ids = list(ids)
         succ, obj, _ = inst.construct(E.GRASP, starts[ids], stream[ids])
         rc, s2, o2, st = inst.two_opt(succ, obj, mode=E.FIRST)
+        if rc != E.OK:
+            raise E.TspDeviceError("alg_2opt on the shard returned status %d" % rc)
         # true cost = sum over nodes of d(v, succ v): one batched spot-distance call (integer costs: any order of the sum is
         # exact; the walk from node 0 that perm_cost needs would be n dependent gathers on the host: 5 of this function's 8 ms)
         n = s2.shape[1]
@@ -194,6 +233,8 @@ def config5_refiner(E, inst, perms):
         np.put_along_axis(succ, p, np.roll(p, -1, axis=1), axis=1)          # perm_to_succ for the whole shard
         cost = inst.perm_cost(p)
         rc, s2, o2, st = inst.two_opt(succ, cost, mode=E.FIRST)
+        if rc != E.OK:
+            raise E.TspDeviceError("alg_2opt on the shard returned status %d" % rc)
         refine.stats = st
         return o2, s2
     return refine
