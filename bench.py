@@ -568,6 +568,7 @@ def main():
         ref = None
         for label, dense in (("from_the_list_of_nonzero_stamps", "0"), ("four_stamp_reads_per_pair", "1")):
             os.environ["TSP_TABU_DENSE"] = dense
+            inst.reload_switches()                     # switches are read when a handle is created, not per call
             tb = E.Tabu(inst)
             tb.set(idx, np.full(live, 5, dtype=np.int32))
             tt = E.Tours(inst, 1)
@@ -585,6 +586,7 @@ def main():
                           "those_bytes_per_s_GBps": 16.0 * pairs_per_sweep * st_t[0]["sweeps"] / dt / 1e9}
             tb.close(); tt.close()
         os.environ.pop("TSP_TABU_DENSE", None)
+        inst.reload_switches()
         res["four_stamp_reads_per_pair"]["hbm_frac"] = res["four_stamp_reads_per_pair"]["those_bytes_per_s_GBps"] / HBM_PEAK_GBS
         res["live_stamps"] = live
         # iterations of tabu() (tabusearch.c:238-309) on resident state: alg_2opt_tabu + incumbent + kick per iteration

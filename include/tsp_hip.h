@@ -42,7 +42,7 @@ enum {
     TSP_TIME_LIMIT_EXCEEDED = 2,  /* include/heuristics.h:7 */
     TSP_DEV_E_NODEVICE = -1,      /* no HIP device / HIP runtime error at init */
     TSP_DEV_E_HIP = -2,           /* a HIP call failed (tsp_dev_last_error() has the text) */
-    TSP_DEV_E_ARG = -3,           /* bad argument (NULL, n < 4, unknown mode ...) */
+    TSP_DEV_E_ARG = -3,           /* bad argument (NULL, n < 3, unknown mode ...) */
     TSP_DEV_E_NOT_A_TOUR = -4,    /* a successor list is not one Hamiltonian cycle */
     TSP_DEV_E_NOMEM = -5,
     TSP_DEV_E_COMM = -6           /* RCCL could not be opened or a collective failed (tsp_dev_comm_last_error()) */
@@ -115,6 +115,11 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
                         int integer_cost, tsp_dev_inst **out);
 void tsp_dev_inst_destroy(tsp_dev_inst *inst);
 int tsp_dev_inst_size(const tsp_dev_inst *inst);
+/* Diagnostics.  The TSP_* environment switches (none changes a result) are read once, when an instance handle is
+ * created; tours / tabu handles take theirs from their instance when THEY are created.  This re-reads them for `inst` (tests
+ * and measurement scripts that run one form of a kernel against another on the same instance); handles created from it
+ * earlier keep what they were created with, except for the cluster / tabu-path choices that are looked up per run. */
+int tsp_dev_inst_reload_switches(tsp_dev_inst *inst);
 
 /* calc_dist(i,j) for `count` index pairs, evaluated on the device (parity / spot checks). */
 int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count, double *out);

@@ -193,6 +193,7 @@ def test_full_size_list_path_equals_per_pair_path(eng, ctx, monkeypatch):
     for dense, engine in (("0", "0"), ("1", "0"), ("0", "1")):   # CLUSTER from the list, GRID per pair, GRID from the list
         monkeypatch.setenv("TSP_TABU_DENSE", dense)
         monkeypatch.setenv("TSP_ENGINE", engine)
+        inst.reload_switches()          # the switches are read when a handle is created, not per call
         tours = eng.Tours(inst, 1)
         tours.upload(s_opt, o_opt)
         tb = eng.Tabu(inst)

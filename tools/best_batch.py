@@ -17,6 +17,7 @@ for name in ("pr299", "att532", "rand800"):
         for force in ("", "1", "3"):
             if force: os.environ["TSP_ENGINE"] = force
             else: os.environ.pop("TSP_ENGINE", None)
+            inst.reload_switches()
             best = None
             for _ in range(3):
                 rc, s, o, st = inst.two_opt(succ, obj, mode=E.BEST)

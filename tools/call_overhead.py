@@ -14,6 +14,7 @@ for name in (sys.argv[1:] or ["rand10000", "pr1002"]):
     succ, obj, _ = inst.construct(E.GREEDY, np.array([0], dtype=np.int32))
     for eng in ("0", "1"):
         os.environ["TSP_ENGINE"] = eng
+        inst.reload_switches()
         tours = E.Tours(inst, 1)
         tours.upload(succ[0], obj[0])
         tb = E.Tabu(inst)

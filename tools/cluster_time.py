@@ -31,8 +31,10 @@ for name in (["rand10000"] if len(sys.argv) > 1 else ["rand10000", "rand5000", "
         for eng, en in ((E.ENGINE_GRID, "GRID"), (E.ENGINE_CLUSTER, "CLUSTER")):
             for C in ([None] if eng == E.ENGINE_GRID else [256, 128, 64]):
                 if C: os.environ["TSP_CLUSTER_BLOCKS"] = str(C)
+                inst.reload_switches()
                 ms, dt, o, st = run(inst, succ[0], obj[0], mode, eng)
                 print("%-10s %-5s %-8s C=%-4s device %.2f ms wall %.2f ms cost %.0f steps %d sweeps %d moves %d -> %.2f us/step"
                       % (name, mn, en, C, ms, 1e3 * dt, o, st["steps"], st["sweeps"], st["moves"], 1e3 * ms / max(1, st["steps"])), flush=True)
                 os.environ.pop("TSP_CLUSTER_BLOCKS", None)
+                inst.reload_switches()
     inst.close()

@@ -14,6 +14,7 @@ inst = E.Instance(ctx, xy, wt, 1)
 succ, obj, _ = inst.construct(E.GREEDY, np.array([0], dtype=np.int32))
 for rpb in sys.argv[1:] or ["16", "32", "64", "128", "256"]:
     os.environ["TSP_BEST_ROWS_PER_BLOCK"] = rpb
+    inst.reload_switches()
     tours = E.Tours(inst, 1)
     tours.upload(succ[0], obj[0])
     best = min(tours.time_scan(50)[0] for _ in range(3))

@@ -15,6 +15,7 @@ for B in (8, 32, 64):
     for force in ("", "1", "3"):
         if force: os.environ["TSP_ENGINE"] = force
         else: os.environ.pop("TSP_ENGINE", None)
+        inst.reload_switches()
         t0 = time.perf_counter()
         rc, s, o, st = inst.two_opt(succ, obj, mode=E.FIRST)
         dt = time.perf_counter() - t0

@@ -18,6 +18,7 @@ perms = np.stack([rng.random_perm(5000) for _ in range(128)])
 for force in (None, "2"):
     if force: os.environ["TSP_ENGINE"] = force
     else: os.environ.pop("TSP_ENGINE", None)
+    inst4.reload_switches(); inst5.reload_switches()
     for world in (1, 2, 4, 8):
         r4 = MS.config4_refiner(E, inst4, starts, stream)
         r5 = MS.config5_refiner(E, inst5, perms)

@@ -1,103 +1,131 @@
-"""Randomised parity sweep (run through gpurun): random sizes around the tile / group / batch boundaries, random metrics
-and cost modes, random tours; both rules, forced sorted sweep / sorted scan, both construction kernels, GRID engine and
-CLUSTER engine with a random cluster size -- all against the oracle.  Prints the first mismatch and exits non-zero.
-SEED=<n> CASES=<n> select the run."""
-import os, sys
+"""Randomised parity sweep: random sizes around the tile / group / batch boundaries, random metrics and cost modes, random
+tours; both rules, forced sorted sweep / sorted scan, both construction kernels, GRID, LDS and CLUSTER engines with a random
+cluster size, a dense random tabu list per small case -- all against the oracle.  `run(seed, cases)` returns the number of
+mismatching cases (it stops at the first); tests/test_gpu_stress.py runs a seeded slice of it under `-m gpu`, and as a
+script (through gpurun) SEED=<n> CASES=<n> select a longer run."""
+import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+if R not in sys.path: sys.path.insert(0, R)
+if os.path.join(R, 'tests') not in sys.path: sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np
-os.environ["TSP_SORTED_MIN_N"] = "0"
-from tsp_optimization_amd import engine as E
-from helpers import random_tour
-from oracle import oracle as O
-ctx = E.Context(0)
-rng = np.random.default_rng(int(os.environ.get("SEED", "1")))
-sizes = [4, 5, 6, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640]   # the CPU oracle bounds the run time
-cases = int(os.environ.get("CASES", "60"))
-bad = 0
-import time
-for c in range(cases):
-    t_case = time.perf_counter()
-    n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(4, 600))
-    if rng.random() < 0.06: n = int(rng.integers(1000, 3000))   # a few larger ones (first improvement only on the CPU side)
-    wt = int(rng.choice([O.EUC_2D, O.ATT, O.CEIL_2D, O.MAN_2D, O.MAX_2D]))
-    ic = int(rng.random() < 0.75)
-    int_coords = rng.random() < 0.5
-    if int_coords: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
-    else: xy = rng.uniform(-5000, 5000, size=(n, 2))
-    # float costs with exactly tied distances (coincident or lattice points) can make the reference's best-improvement
-    # loop cycle forever on rounding-noise deltas (seen: ATT, 127 points on a 20 x 20 lattice): integer costs there
-    if int_coords: ic = 1
-    if wt == O.CEIL_2D: ic = 1
-    # float costs on MAN_2D / MAX_2D (dy = |y2 - y2| = 0 in the reference) can cycle forever on rounding noise: the
-    # reference relies on its time limit there, and so would this run
-    if wt in (O.MAN_2D, O.MAX_2D): ic = 1
-    inst = E.Instance(ctx, xy, wt, ic)
-    s0 = int(rng.integers(0, n))
-    succ, obj, _ = inst.construct(E.GREEDY, np.array([s0], dtype=np.int32))
-    _, es, eo = O.greedy(xy, wt, start=s0, integer_cost=ic)
-    ok = (succ[0] == es).all() and obj[0] == eo
-    tour = random_tour(n, rng) if rng.random() < 0.5 else es
-    cost = O.succ_cost(xy, wt, tour, integer_cost=ic)
-    if n <= 300:   # the oracle's best-improvement descent from a random tour is O(n^3)
-        rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=1)
-        _, bs, bo, bst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic)
-        ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
-    rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
-    _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
-    ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
-    # the same two descents on the CLUSTER engine with a random number of workgroups per tour
-    os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 8, 17, 64, 200, 256])))
-    if n <= 300:
-        rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)
-        ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
-    rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
-    ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
-    del os.environ["TSP_CLUSTER_BLOCKS"]
-    if n <= 8000:   # the LDS engine (one workgroup per tour), first improvement, with and without the probe
-        os.environ["TSP_LDS_PROBE"] = str(int(rng.choice([0, 1, 600, 1 << 30])))
-        rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=2)
-        del os.environ["TSP_LDS_PROBE"]
+SIZES = [3, 4, 5, 6, 7, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640]   # the CPU oracle bounds the run time
+
+
+def run(seed, cases, ctx=None, verbose=True, max_n=3000):
+    prev = os.environ.get("TSP_SORTED_MIN_N")
+    os.environ["TSP_SORTED_MIN_N"] = "0"
+    try:
+        return _run(seed, cases, ctx, verbose, max_n)
+    finally:
+        if prev is None: os.environ.pop("TSP_SORTED_MIN_N", None)
+        else: os.environ["TSP_SORTED_MIN_N"] = prev
+        for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE"): os.environ.pop(k, None)
+
+
+def _run(seed, cases, ctx, verbose, max_n):
+    from tsp_optimization_amd import engine as E
+    from helpers import random_tour
+    from oracle import oracle as O
+    own = ctx is None
+    if own: ctx = E.Context(0)
+    rng = np.random.default_rng(seed)
+    sizes = SIZES
+    bad = 0
+    for c in range(cases):
+        t_case = time.perf_counter()
+        n = int(rng.choice(sizes)) if rng.random() < 0.6 else int(rng.integers(3, 600))
+        if rng.random() < 0.06 and max_n > 1000: n = int(rng.integers(1000, max_n))   # a few larger ones (first improvement only on the CPU side)
+        wt = int(rng.choice([O.EUC_2D, O.ATT, O.CEIL_2D, O.MAN_2D, O.MAX_2D]))
+        ic = int(rng.random() < 0.75)
+        int_coords = rng.random() < 0.5
+        if int_coords: xy = rng.integers(0, int(rng.choice([20, 1000, 1000000])), size=(n, 2)).astype(np.float64)
+        else: xy = rng.uniform(-5000, 5000, size=(n, 2))
+        # float costs with exactly tied distances (coincident or lattice points) can make the reference's best-improvement
+        # loop cycle forever on rounding-noise deltas (seen: ATT, 127 points on a 20 x 20 lattice): integer costs there
+        if int_coords: ic = 1
+        if wt == O.CEIL_2D: ic = 1
+        # float costs on MAN_2D / MAX_2D (dy = |y2 - y2| = 0 in the reference) can cycle forever on rounding noise: the
+        # reference relies on its time limit there, and so would this run
+        if wt in (O.MAN_2D, O.MAX_2D): ic = 1
+        inst = E.Instance(ctx, xy, wt, ic)
+        s0 = int(rng.integers(0, n))
+        succ, obj, _ = inst.construct(E.GREEDY, np.array([s0], dtype=np.int32))
+        _, es, eo = O.greedy(xy, wt, start=s0, integer_cost=ic)
+        ok = (succ[0] == es).all() and obj[0] == eo
+        tour = random_tour(n, rng) if rng.random() < 0.5 else es
+        cost = O.succ_cost(xy, wt, tour, integer_cost=ic)
+        if n <= 300:   # the oracle's best-improvement descent from a random tour is O(n^3)
+            rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=1)
+            _, bs, bo, bst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic)
+            ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+        rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
+        _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
         ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
-    if 4 <= n <= 220:
-        # alg_2opt_tabu with a dense random tabu list (live and expired stamps, tour edges included): the list path
-        it, ten = int(rng.integers(2, 40)), int(rng.integers(0, 15))
-        stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
-        for _ in range(int(rng.choice([1, n // 2, 2 * n]))):
-            a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
-            if rng.random() < 0.4: b = int(tour[a])
-            if a != b: stamps[min(a, b) * n + max(a, b) - (min(a, b) + 1) * (min(a, b) + 2) // 2] = int(rng.integers(1, it + 1))
-        exp = stamps.copy()
-        _, ts, to, tst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic, tabu=exp, iter_=it, tenure=ten)
-        tb = E.Tabu(inst)
-        tb.upload(stamps)
-        rc, s, o, st, _ = tb.two_opt(tour, it, ten)
-        ok = ok and (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"])
-        ok = ok and (tb.download() == exp).all() and tb.list_info()[1]
-        tb.close()
-    if c % 3 == 0 and n >= 8:
-        # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
-        t3 = np.stack([random_tour(n, rng) for _ in range(3)])
-        c3 = np.array([O.succ_cost(xy, wt, t, integer_cost=ic) for t in t3])
-        rc, s3, o3, st3 = inst.two_opt(t3, c3, mode=E.FIRST)
-        os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 7, 33, 85])))
-        rc, s4, o4, st4 = inst.two_opt(t3, c3, mode=E.FIRST, engine=3)      # three clusters side by side
+        # the same two descents on the CLUSTER engine with a random number of workgroups per tour
+        os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 8, 17, 64, 200, 256])))
+        inst.reload_switches()
+        if n <= 300:
+            rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)
+            ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+        rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
+        ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
         del os.environ["TSP_CLUSTER_BLOCKS"]
-        for b in range(3):
-            _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
-            ok = ok and (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"]
-            ok = ok and (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"]
-        O.srandom(1000 + c)
-        ur = np.array([[O.urand() for _ in range(n)]])
-        O.srandom(1000 + c)
-        _, gs, go = O.grasp(xy, wt, start=s0, integer_cost=ic)
-        sg, og, _ = inst.construct(E.GRASP, np.array([s0], dtype=np.int32), ur)
-        ok = ok and (sg[0] == gs).all() and og[0] == go
-    inst.close()
-    print("case %d n %d wt %d ic %d %s  %.2f s" % (c, n, wt, ic, "ok" if ok else "MISMATCH", time.perf_counter() - t_case), flush=True)
-    if not ok:
-        bad += 1
-        print("MISMATCH case %d: n %d wt %d ic %d" % (c, n, wt, ic))
-        break
-print("cases %d, mismatches %d" % (c + 1, bad))
-sys.exit(1 if bad else 0)
+        inst.reload_switches()
+        if n <= 8000:   # the LDS engine (one workgroup per tour), first improvement, with and without the probe
+            os.environ["TSP_LDS_PROBE"] = str(int(rng.choice([0, 1, 600, 1 << 30])))
+            inst.reload_switches()
+            rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=2)
+            del os.environ["TSP_LDS_PROBE"]
+            inst.reload_switches()
+            ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+        if 4 <= n <= 220:
+            # alg_2opt_tabu with a dense random tabu list (live and expired stamps, tour edges included): the list path
+            it, ten = int(rng.integers(2, 40)), int(rng.integers(0, 15))
+            stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
+            for _ in range(int(rng.choice([1, n // 2, 2 * n]))):
+                a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+                if rng.random() < 0.4: b = int(tour[a])
+                if a != b: stamps[min(a, b) * n + max(a, b) - (min(a, b) + 1) * (min(a, b) + 2) // 2] = int(rng.integers(1, it + 1))
+            exp = stamps.copy()
+            _, ts, to, tst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic, tabu=exp, iter_=it, tenure=ten)
+            tb = E.Tabu(inst)
+            tb.upload(stamps)
+            rc, s, o, st, _ = tb.two_opt(tour, it, ten)
+            ok = ok and (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"])
+            ok = ok and (tb.download() == exp).all() and tb.list_info()[1]
+            tb.close()
+        if c % 3 == 0 and n >= 8:
+            # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
+            t3 = np.stack([random_tour(n, rng) for _ in range(3)])
+            c3 = np.array([O.succ_cost(xy, wt, t, integer_cost=ic) for t in t3])
+            rc, s3, o3, st3 = inst.two_opt(t3, c3, mode=E.FIRST)
+            os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 7, 33, 85])))
+            inst.reload_switches()
+            rc, s4, o4, st4 = inst.two_opt(t3, c3, mode=E.FIRST, engine=3)      # three clusters side by side
+            del os.environ["TSP_CLUSTER_BLOCKS"]
+            inst.reload_switches()
+            for b in range(3):
+                _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
+                ok = ok and (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"]
+                ok = ok and (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"]
+            O.srandom(1000 + c)
+            ur = np.array([[O.urand() for _ in range(n)]])
+            O.srandom(1000 + c)
+            _, gs, go = O.grasp(xy, wt, start=s0, integer_cost=ic)
+            sg, og, _ = inst.construct(E.GRASP, np.array([s0], dtype=np.int32), ur)
+            ok = ok and (sg[0] == gs).all() and og[0] == go
+        inst.close()
+        if verbose: print("case %d n %d wt %d ic %d %s  %.2f s" % (c, n, wt, ic, "ok" if ok else "MISMATCH", time.perf_counter() - t_case), flush=True)
+        if not ok:
+            bad += 1
+            print("MISMATCH case %d: n %d wt %d ic %d" % (c, n, wt, ic))
+            break
+    if own: ctx.close()
+    return bad
+
+
+if __name__ == "__main__":
+    n_cases = int(os.environ.get("CASES", "60"))
+    n_bad = run(int(os.environ.get("SEED", "1")), n_cases)
+    print("cases %d, mismatches %d" % (n_cases, n_bad))
+    sys.exit(1 if n_bad else 0)

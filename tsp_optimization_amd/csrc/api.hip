@@ -34,6 +34,18 @@ void *tsp_io_pool(tsp_dev_inst *inst, size_t bytes) {
 }
 
 namespace tsp {
+void read_switches(Switches *sw) {
+    static const char *const names[SW_COUNT] = {
+#define TSP_SW_NAME(name) "TSP_" #name,
+        TSP_SWITCH_LIST(TSP_SW_NAME)
+#undef TSP_SW_NAME
+    };
+    for (int k = 0; k < SW_COUNT; ++k) {
+        const char *v = getenv(names[k]);
+        sw->has[k] = v && *v;
+        sw->v[k] = sw->has[k] ? atoi(v) : 0;
+    }
+}
 static thread_local char g_last_error[512] = "";
 void set_last_error(const char *what, hipError_t e, const char *file, int line) {
     snprintf(g_last_error, sizeof g_last_error, "%s:%d: %s -> %s", file, line, what, hipGetErrorString(e));
@@ -186,6 +198,11 @@ int tsp_dev_open(int device, tsp_dev_ctx **out) {
     TSP_HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
     c->lds_bytes = (int)prop.sharedMemPerBlock;
+    {   // what one workgroup may be granted with hipFuncAttributeMaxDynamicSharedMemorySize (160 KiB on gfx950)
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && optin > c->lds_bytes)
+            c->lds_bytes = optin;
+    }
     TSP_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     guard.c = nullptr;
     *out = c;
@@ -209,7 +226,7 @@ void *tsp_dev_stream(tsp_dev_ctx *ctx) { return ctx ? (void *)ctx->stream : null
 
 int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_type, int integer_cost,
                         tsp_dev_inst **out) {
-    if (!ctx || !xy || !out || n < 4) return TSP_DEV_E_ARG;
+    if (!ctx || !xy || !out || n < 3) return TSP_DEV_E_ARG;   // three nodes: one tour, nothing to improve (the reference runs it)
     TSP_HIP_TRY(hipSetDevice(ctx->device));
     tsp_dev_inst *inst = new tsp_dev_inst();
     inst->ctx = ctx;
@@ -220,6 +237,7 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
     inst->integer_cost = integer_cost ? 1 : 0;
     inst->wtype_public = inst->wtype;
     inst->h_xy.assign(xy, xy + 2 * (size_t)n);
+    tsp::read_switches(&inst->sw);
     {   // integer coordinates of bounded span: switch to the exact integer-root variants (tsp_dist.hpp)
         bool all_int = true;
         double lox = xy[0], hix = xy[0], loy = xy[1], hiy = xy[1];
@@ -233,26 +251,24 @@ int tsp_dev_inst_create(tsp_dev_ctx *ctx, const double *xy, int n, int weight_ty
         inst->cost_bound = span + 2.0;
         {   // root filter margin: two raw roots (each within r * 2^-23 of r <= span, taken at 2^-22 for slack)
             // + the rounding the exact metric adds to each of the two distances (nint 0.5, ceil/ATT < 1)
-            const char *nof = getenv("TSP_NO_FILTER");
+            const bool nof = TSP_SW(inst, NO_FILTER, 0) == 1, nop = TSP_SW(inst, NO_PRUNE, 0) == 1;
             const bool sqrt_metric = inst->wtype == TSP_EUC_2D || inst->wtype == TSP_CEIL_2D || inst->wtype == TSP_ATT;
             inst->filter_margin = 1e300;   // "off": no pair is ever skipped
-            if (sqrt_metric && !(nof && *nof == '1') && span < 1e100) {
+            if (sqrt_metric && !nof && span < 1e100) {
                 const double rounding = (inst->integer_cost || inst->wtype == TSP_CEIL_2D) ? 2.0 : 0.0;
                 inst->filter_margin = 2.0 * span * 0x1p-22 + rounding + 1e-6 + span * 0x1p-40;
             }
             // new-edge bound: nint() can shorten the new edge by at most 1/2 (ceil / ATT never shorten it);
             // the slack covers the rounding of s, T*T and the sums for coordinates of this magnitude
-            const char *nop = getenv("TSP_NO_PRUNE");
             inst->prune_margin = 1e300;
-            if (sqrt_metric && !(nop && *nop == '1') && !(nof && *nof == '1') && span < 1e100)
+            if (sqrt_metric && !nop && !nof && span < 1e100)
                 inst->prune_margin = ((inst->integer_cost && inst->wtype == TSP_EUC_2D) ? 0.5 : 0.0) + 1e-6 + span * 0x1p-36;
             // both new edges: nint() shortens each by at most 1/2; slack doubled so that '<' keeps ties.  The test
             // multiplies squared distances: only for spans whose fourth power is far from overflow.
             if (inst->prune_margin < 1e299 && span < 1e60)
                 inst->sum_margin = ((inst->integer_cost && inst->wtype == TSP_EUC_2D) ? 1.0 : 0.0) + 2e-6 + span * 0x1p-34;
         }
-        const char *off = getenv("TSP_NO_ICOORD");
-        if (all_int && span < TSP_ICOORD_MAX_DIST && !(off && *off == '1')) {
+        if (all_int && span < TSP_ICOORD_MAX_DIST && TSP_SW(inst, NO_ICOORD, 0) != 1) {
             if (inst->wtype == TSP_EUC_2D && inst->integer_cost) inst->wtype = tsp::WT_EUC_2D_ICOORD;
             else if (inst->wtype == TSP_ATT && inst->integer_cost) inst->wtype = tsp::WT_ATT_ICOORD;
             else if (inst->wtype == TSP_CEIL_2D) { inst->wtype = tsp::WT_CEIL_2D_ICOORD; }
@@ -318,6 +334,17 @@ void tsp_dev_inst_destroy(tsp_dev_inst *inst) {
 }
 
 int tsp_dev_inst_size(const tsp_dev_inst *inst) { return inst ? inst->n : 0; }
+
+int tsp_dev_inst_reload_switches(tsp_dev_inst *inst) {
+    if (!inst) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
+    TSP_HIP_TRY(hipStreamSynchronize(inst->ctx->stream));
+    // the cached single-tour / batch handles were laid out under the old switches
+    if (inst->scratch1) { tsp_dev_tours_destroy(inst->scratch1); inst->scratch1 = nullptr; }
+    if (inst->scratch_b) { tsp_dev_tours_destroy(inst->scratch_b); inst->scratch_b = nullptr; inst->scratch_b_count = 0; }
+    tsp::read_switches(&inst->sw);
+    return TSP_OK;
+}
 
 int tsp_dev_dist_pairs(tsp_dev_inst *inst, const int *i, const int *j, int count, double *out) {
     if (!inst || !i || !j || !out || count < 0) return TSP_DEV_E_ARG;
@@ -407,10 +434,12 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         //    tour, whole descent in one launch.  A step costs one exchange through L2 instead of one or two kernel boundaries.
         //  * LDS (one workgroup per tour): first-improvement batches of more tours than an eighth of the CUs.
         //  * GRID: everything else (tours beyond LDS, tabu runs, large best-improvement batches).
-        const char *force = getenv("TSP_ENGINE");
+        const int force = TSP_SW(inst, ENGINE, 0);
         const bool lds_ok = tsp_lds_fits(inst);
         const int C = tsp_cluster_fits(t, mode) ? tsp_cluster_size(t, mode) : 0;
-        bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= 8;
+        // "few tours" / "most of the chip idle" in units of this device's CUs: 1/32 of them (8 on the 256 CUs of an MI355X)
+        const int few = std::max(1, inst->ctx->num_cus / 32);
+        bool lds = lds_ok && mode == TSP_2OPT_FIRST && B >= few;
         // few tours: CLUSTER whatever the cluster size (measured on single tours from berlin52 to rand10000, tools/cluster_time.py:
         // 1.4-2.6 x faster than GRID in both rules, level with LDS at n = 52, 1.6 x faster at n = 299); eight or more tours: one
         // workgroup per tour (LDS, first improvement) unless that would leave most of the chip idle (C >= 8), best-improvement
@@ -419,10 +448,11 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         // size that fits the chip, one workgroup per tour included -- tools/best_batch.py)
         // (first-improvement batches the LDS engine cannot hold -- n > ~8000 -- go to the cluster at any size: 64 tours of
         // rand10000 on 4 workgroups each 117 ms, GRID 240 ms -- tools/first_batch_big.py)
-        bool cluster = C >= 1 && (B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (C >= 8 || !lds_ok)));
-        if (force && *force == '1') { lds = false; cluster = false; }
-        if (force && *force == '2' && lds_ok) { lds = true; cluster = false; }
-        if (force && *force == '3' && C >= 1) cluster = true;
+        bool cluster = C >= 1 && (B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (C >= few || !lds_ok)));
+        if (cluster && force != 3 && inst->ctx->cl_skip > 0) { --inst->ctx->cl_skip; cluster = false; }   // backing off after a give-up
+        if (force == 1) { lds = false; cluster = false; }
+        if (force == 2 && lds_ok) { lds = true; cluster = false; }
+        if (force == 3 && C >= 1) cluster = true;
         engine = cluster ? TSP_ENGINE_CLUSTER : (lds ? TSP_ENGINE_LDS : TSP_ENGINE_GRID);
         cluster_C = std::max(1, C);
     }
@@ -464,8 +494,10 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
 
 static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t max_steps, double time_limit_s, int *all_done) {
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
-        const bool want = engine == TSP_ENGINE_CLUSTER ||
-                          (tsp_cluster_fits(t, mode) && (t->B < 8 || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (tsp_cluster_size(t, mode) >= 8 || !tsp_lds_fits(t->inst)))));
+        const int few = std::max(1, t->inst->ctx->num_cus / 32);   // as in tsp_dev_two_opt
+        bool want = engine == TSP_ENGINE_CLUSTER ||
+                    (tsp_cluster_fits(t, mode) && (t->B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (tsp_cluster_size(t, mode) >= few || !tsp_lds_fits(t->inst)))));
+        if (want && engine == TSP_ENGINE_AUTO && t->inst->ctx->cl_skip > 0) { --t->inst->ctx->cl_skip; want = false; }   // backing off after a give-up
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;
             int fell = 0;

@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <mutex>
 
@@ -72,6 +73,21 @@ const Rccl *rccl() {
 }
 
 }  // namespace
+
+// RCCL prints a version banner on stdout when a communicator is formed.  The reference's CLI protocol is a bare number on
+// stdout (src/solver.c:291-292), so while a communicator is being formed stdout is pointed at stderr.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    }
+};
 
 struct tsp_dev_comm {
     tsp_dev_ctx *ctx = nullptr;
@@ -134,7 +150,10 @@ int tsp_dev_comm_init_rank(tsp_dev_ctx *ctx, int world, int rank, const char *id
     struct Guard { tsp_dev_comm *c; ~Guard() { if (c) tsp_dev_comm_destroy(c); } } guard{c};
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    TSP_NCCL_TRY(R->CommInitRank(&c->comm, world, u, rank));
+    {
+        StdoutToStderr quiet;
+        TSP_NCCL_TRY(R->CommInitRank(&c->comm, world, u, rank));
+    }
     int rc = comm_alloc(c);
     if (rc) return rc;
     guard.c = nullptr;
@@ -154,7 +173,10 @@ int tsp_dev_comm_init_all(tsp_dev_ctx *const *ctxs, int ndev, tsp_dev_comm **out
         for (int q = 0; q < k; ++q) if (devs[q] == devs[k]) return TSP_DEV_E_ARG;   // one rank per device
         out[k] = nullptr;
     }
-    TSP_NCCL_TRY(R->CommInitAll(comms, ndev, devs));
+    {
+        StdoutToStderr quiet;
+        TSP_NCCL_TRY(R->CommInitAll(comms, ndev, devs));
+    }
     for (int k = 0; k < ndev; ++k) {
         tsp_dev_comm *c = new tsp_dev_comm();
         c->ctx = ctxs[k]; c->comm = comms[k]; c->rank = k; c->world = ndev;

@@ -671,7 +671,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
     // greedy on a sqrt metric with the Hilbert groups at hand: the spatial kernel, one wave per start
     bool use_nn = false;
     {
-        const char *off = getenv("TSP_CONSTRUCT_NN");
+        const bool nn_off = TSP_SW(inst, CONSTRUCT_NN, 1) == 0;
         const bool icoord = inst->wtype == tsp::WT_EUC_2D_ICOORD || inst->wtype == tsp::WT_CEIL_2D_ICOORD || inst->wtype == tsp::WT_ATT_ICOORD;
         const size_t need = icoord ? nn_lds_bytes<float2>(inst->n_slots, inst->ng) : nn_lds_bytes<double2>(inst->n_slots, inst->ng);
         const bool small = inst->ng <= 64 * kNnMaxRounds && need <= (size_t)158 * 1024;
@@ -679,7 +679,7 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
         const size_t need_big = (sizeof(float4) + sizeof(unsigned long long)) * (size_t)inst->ng + 64;
         const bool big = !small && inst->ng <= 4096 && need_big <= (size_t)158 * 1024;
         // greedy: both kernels; grasp (its runner-up is one more query with an id limit): the LDS-resident one
-        use_nn = inst->d_sperm && !(off && *off == '0') && (small || (big && kind == TSP_CONSTRUCT_GREEDY));
+        use_nn = inst->d_sperm && !nn_off && (small || (big && kind == TSP_CONSTRUCT_GREEDY));
         // one 64-bit key per candidate when the costs are integers and ids/slots fit their fields
         const bool pack = inst->integer_cost && (small ? (inst->n_slots <= 32768 && inst->cost_bound < 2147483647.0)
                                                        : (inst->n_slots <= 262144 && inst->cost_bound < 268435455.0));
@@ -720,9 +720,8 @@ int tsp_dev_construct(tsp_dev_inst *inst, int kind, int B, const int *starts, co
             TSP_HIP_TRY(e_nn);
         }
     }
-    const char *no_lds = getenv("TSP_CONSTRUCT_GLOBAL");
     const size_t lds_bytes = 4 * (kConsLdsThreads / 64) * sizeof(ConsSlot) + sizeof(double2) * (size_t)n;
-    const bool use_lds = !(no_lds && *no_lds == '1') && n <= kConsLdsMaxN && lds_bytes <= (size_t)160 * 1024;
+    const bool use_lds = TSP_SW(inst, CONSTRUCT_GLOBAL, 0) != 1 && n <= kConsLdsMaxN && lds_bytes <= (size_t)160 * 1024;
     hipError_t attr_err = hipSuccess;
     if (!use_nn) TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, {
         if (use_lds) {

@@ -46,13 +46,42 @@ constexpr int kApplyThreads = 1024;
 
 }  // namespace tsp
 
+// ---- switches: TSP_<NAME> environment variables.  None of them changes a result.  They are read ONCE per
+// instance handle (tsp_dev_inst_create) into this table; nothing on a call path calls getenv. ------------------------------
+#define TSP_SWITCH_LIST(X)                                                                                                  \
+    X(ENGINE) X(CLUSTER_BLOCKS) X(CLUSTER_MIN_ROWS) X(CLUSTER_MAX_ROWS) X(CLUSTER_HIT_CAP) X(CLUSTER_SPIN_LIMIT)            \
+    X(CLUSTER_SPIN_MS) X(CLUSTER_ALLOW_OVERSUB) X(CLUSTER_DEBUG) X(CLUSTER_PROBE) X(CLUSTER_FIRST_SORTED) X(TABU_DENSE)     \
+    X(LDS_PROBE) X(LDS_PROBE2) X(LDS_MIN_ROWS) X(LDS_EDGE_CACHE) X(NO_ICOORD) X(NO_FILTER) X(NO_PRUNE) X(SORTED_MIN_N)      \
+    X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
+    X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \
+    X(CONSTRUCT_NN) X(LDS_PAIR)
+namespace tsp {
+enum SwitchId {
+#define TSP_SW_ENUM(name) SW_##name,
+    TSP_SWITCH_LIST(TSP_SW_ENUM)
+#undef TSP_SW_ENUM
+    SW_COUNT
+};
+struct Switches {
+    int v[SW_COUNT];
+    bool has[SW_COUNT];
+    int get(SwitchId k, int dflt) const { return has[k] ? v[k] : dflt; }
+};
+void read_switches(Switches *sw);   // api.hip
+}  // namespace tsp
+#define TSP_SW(inst_, NAME, dflt) ((inst_)->sw.get(tsp::SW_##NAME, (dflt)))
+
 // ---- opaque handles ------------------------------------------------------------------------
 
 struct tsp_dev_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    int lds_bytes = 0;
+    int lds_bytes = 0;        // LDS one workgroup may be granted (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on gfx950)
+    // CLUSTER engine under AUTO: after a give-up (a workgroup was not resident: the device is shared or CU-masked) the next
+    // `cl_skip` AUTO decisions go to the other engines; the back-off doubles with every further give-up (64 .. 4096 calls)
+    int cl_skip = 0, cl_backoff = 0;
+    long long cl_giveups = 0;
 };
 
 namespace tsp { struct NodeRec; }
@@ -89,6 +118,7 @@ struct tsp_dev_inst {
     double2 *d_rcoord = nullptr;       // CLUSTER engine, sorted scan: coordinates in rank order, padding far away (ng * 64)
     int *d_sinv = nullptr;             // CLUSTER engine, sorted scan: node -> rank slot
     std::vector<double> h_xy;   // host copy of the raw coordinates (2n)
+    tsp::Switches sw;           // the TSP_* switches as they stood when this handle was created
 };
 
 struct tsp_dev_tabu {

@@ -41,7 +41,9 @@ constexpr int kClListCap = kClThreads;   // surviving group pairs a workgroup ho
 
 constexpr int kClQueue = 128;      // per-wave ring of pairs waiting for tiers 1 and 2 (entries; a power of two >= 128)
 constexpr int kClSlotGranules = 4; // granules per workgroup and parity in the exchange area
-constexpr unsigned kClSpinLimit = 1u << 20;   // sweeps of the exchange area before a workgroup gives up (~ seconds)
+constexpr unsigned kClSpinLimit = 1u << 20;   // sweeps of the exchange area before a workgroup gives up (~ seconds): the backstop
+constexpr int kClSpinMs = 50;                 // ... and the time a workgroup waits for its peers' tags (TSP_CLUSTER_SPIN_MS): a step
+                                              // takes microseconds, so tens of milliseconds without a tag mean a peer is not resident
 using idx_t = unsigned short;
 using gu64 = __attribute__((address_space(1))) unsigned long long;
 using gi32c = __attribute__((address_space(1))) int;
@@ -79,7 +81,8 @@ struct ClusterArgs {
     unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
-    unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up
+    unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up ...
+    unsigned long long spin_ticks;   // ... or this much time (100 MHz ticks) without the peers' tags, whichever comes first
     int dbg;                // diagnostics (TSP_CLUSTER_DEBUG): 1 rebuild every group bound per step, 2 no row culling, 4 no box test
     double org_x, org_y;    // float replicas hold coordinates relative to this corner (exact: bounded integers)
     double margin, prune, sum_margin;
@@ -220,7 +223,8 @@ struct ClCand {
 // everybody has published s + 1, i.e. has finished reading s), so parity s is never rewritten while somebody still
 // reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
 template <bool BEST, bool SORTED, bool SMALLD>
-__device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err, unsigned spin_limit) {
+__device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err, unsigned spin_limit,
+                                            unsigned long long spin_ticks) {
     constexpr int NG = 1 + (SORTED ? 1 : 0) + (SMALLD ? 1 : 2);
     constexpr int GD = SORTED ? 2 : 1;   // first delta granule
     const int lane = threadIdx.x & 63;
@@ -244,6 +248,7 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
 #pragma unroll
     for (int q = 0; q < Q; ++q) have[q] = q * 64 + lane >= C;
     unsigned spins = 0;
+    unsigned long long t_wait = 0;   // when the 64th sweep without all tags began (a sweep is ~1 us: most exchanges never read the clock)
     for (;;) {
         bool ok = true;
 #pragma unroll
@@ -263,7 +268,14 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
             }
         }
         if (__all(ok)) break;
-        if (++spins > spin_limit ||
+        ++spins;
+        bool late = spins > spin_limit;
+        if ((spins & 63u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t_wait == 0) t_wait = now;
+            late = late || now - t_wait > spin_ticks;
+        }
+        if (late ||
             ((spins & 1023u) == 0 && __hip_atomic_load((gi32c *)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             if (lane == 0) __hip_atomic_store((gi32c *)err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
@@ -415,7 +427,22 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 #endif
     unsigned xep = a.epoch0;   // exchange epochs (a step decided by the probe has none); slots hold smaller ones from earlier launches
     bool probe_on = true;    // FIRST: the last hit lay close to the cursor (every workgroup keeps the same value)
-    for (int iter = 0; iter < a.max_iters && !done; ++iter) {
+    if constexpr (!BEST) {
+        // Arrival rendezvous.  A first-improvement launch whose steps are all decided by the probe exchanges nothing, so the
+        // cluster's first workgroup could reach its write-back of order[] / pos[] / the control block while a workgroup that
+        // was dispatched late is still loading them: one (empty) exchange after the replica load -- nobody passes it before
+        // everybody has loaded.  (Best improvement exchanges in every step: its first step is the rendezvous.)
+        if (C > 1) {
+            if (wave == 0) {
+                ClCand none{0.0, kNoKey, 0u};
+                const bool okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, none, a.err, a.spin_limit, a.spin_ticks);
+                if (lane == 0) *s_fail = okx ? 0 : 1;
+            }
+            __syncthreads();
+            if (*s_fail) failed = true;
+        }
+    }
+    for (int iter = 0; iter < a.max_iters && !done && !failed; ++iter) {
         int row_lo = 0, row_hi = n - 1;
         double bd = 0.0;
         u64 key = kNoKey;
@@ -836,7 +863,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
-            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit);
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
         }
         if constexpr (TABU) {
@@ -1081,12 +1108,9 @@ double wall_s() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
-constexpr size_t kLdsLimit = (size_t)160 * 1024;
+// LDS one workgroup may have: what the device grants (160 KiB on gfx950)
+size_t cl_lds_limit(const tsp_dev_ctx *ctx) { return ctx->lds_bytes > 0 ? (size_t)ctx->lds_bytes : (size_t)64 * 1024; }
 
 // ICOORD variants: coordinates are integers of bounded span -> exact as floats relative to the instance corner
 template <int WT>
@@ -1116,7 +1140,7 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs
     for (p.stage_pairs = p.sorted ? kClMaxStagePairs : 0;; --p.stage_pairs) {
         p.lds = cl_layout(inst->n, p.nid, inst->ng, ce, p.sorted, p.stage_pairs).total;
-        p.ok = p.lds <= kLdsLimit;
+        p.ok = p.lds <= cl_lds_limit(inst->ctx);
         if (p.ok || p.stage_pairs <= 1) break;
     }
     return p;
@@ -1186,7 +1210,7 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode) {
         // (measured, one tour: n = 532 / 1002 / 2000 are 10 % faster on 64 workgroups than on 256, n >= 5000 on 256)
         if (mode == TSP_2OPT_FIRST) C = (int)std::max<long long>(1, std::min<long long>(C, 32 * nb));
     }
-    return std::max(1, env_int("TSP_CLUSTER_BLOCKS", C));
+    return std::max(1, TSP_SW(t->inst, CLUSTER_BLOCKS, C));
 }
 
 // Runs the tours of `t` to their local optima with C workgroups per tour.  Returns TSP_DEV_E_HIP with
@@ -1204,7 +1228,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     hipStream_t s = inst->ctx->stream;
     const int n = t->n, B = t->B;
     // all workgroups must be resident (TSP_CLUSTER_ALLOW_OVERSUB=1 lifts the check: the tests use it to drive the give-up path)
-    if (C > 1 && (long long)B * C > std::max(1, inst->ctx->num_cus) && !env_int("TSP_CLUSTER_ALLOW_OVERSUB", 0)) return TSP_DEV_E_ARG;
+    if (C > 1 && (long long)B * C > std::max(1, inst->ctx->num_cus) && !TSP_SW(inst, CLUSTER_ALLOW_OVERSUB, 0)) return TSP_DEV_E_ARG;
 
     // per-instance tables of the sorted scan: coordinates in rank order (padding far away), node -> rank
     if (p.sorted && !inst->d_rcoord) {
@@ -1275,10 +1299,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu = tabu->d_stamp; a.tabu_list = tabu->d_list; a.tabu_list_n = tabu->d_list_n; a.tabu_list_cap = tabu->list_cap;
         a.tabu_side = tabu->d_tabu_pairs;
     }
-    a.probe = env_int("TSP_CLUSTER_PROBE", 4096);
-    a.dbg = env_int("TSP_CLUSTER_DEBUG", 0);
+    a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
+    a.dbg = TSP_SW(inst, CLUSTER_DEBUG, 0);
     a.stage_pairs = p.stage_pairs;
-    a.spin_limit = (unsigned)std::max(16, env_int("TSP_CLUSTER_SPIN_LIMIT", (int)kClSpinLimit));
+    a.spin_limit = (unsigned)std::max(16, TSP_SW(inst, CLUSTER_SPIN_LIMIT, (int)kClSpinLimit));
+    a.spin_ticks = (unsigned long long)std::max(1, TSP_SW(inst, CLUSTER_SPIN_MS, kClSpinMs)) * 100000ull;   // 100 MHz
     a.org_x = inst->org_x; a.org_y = inst->org_y;
     a.margin = inst->filter_margin; a.prune = inst->prune_margin; a.sum_margin = inst->sum_margin;
     // FIRST chunk geometry: the chunk adapts to the distance between hits (see the kernel's control block); the largest
@@ -1286,11 +1311,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     {   // rows that cost (almost) nothing more than one: every workgroup at most one tile of at most two rows (measured:
         // rand10000 on 256 workgroups is best at 24-36 rows, 16 random tours of rand5000 on 16 workgroups each at 1-2)
         const int nb = (n + kClThreads - 1) / kClThreads;
-        a.rmin = std::max(1, std::min(2048, env_int("TSP_CLUSTER_MIN_ROWS", std::max(1, 2 * (C / nb)))));
-        a.rcap = std::max(a.rmin, env_int("TSP_CLUSTER_HIT_CAP", 4) * a.rmin);   // largest chunk right after a hit
+        a.rmin = std::max(1, std::min(2048, TSP_SW(inst, CLUSTER_MIN_ROWS, std::max(1, 2 * (C / nb)))));
+        a.rcap = std::max(a.rmin, TSP_SW(inst, CLUSTER_HIT_CAP, 4) * a.rmin);   // largest chunk right after a hit
         a.rbs = C / nb;
     }
-    a.rmax = std::max(a.rmin, std::min(2048, env_int("TSP_CLUSTER_MAX_ROWS", C == 1 ? kClRows : std::max(kClRows, 8 * C))));
+    a.rmax = std::max(a.rmin, std::min(2048, TSP_SW(inst, CLUSTER_MAX_ROWS, C == 1 ? kClRows : std::max(kClRows, 8 * C))));
     // steps per launch: a time limit is honoured between launches (the reference checks it per sweep / per pair), so a
     // limited run is cut into launches of a millisecond or two (a relaunch reloads the replicas: ~0.1 ms)
     const int launch_iters = time_limit_s > 0 ? (mode == TSP_2OPT_FIRST ? 256 : 128) : (mode == TSP_2OPT_FIRST ? 16384 : 4096);
@@ -1298,6 +1323,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     const double t0 = wall_s();
     int status = TSP_OK;
     int64_t queued = 0;
+    int launches_done = 0;
     for (;;) {
         a.max_iters = launch_iters;
         if (max_steps >= 0) {
@@ -1307,15 +1333,22 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         queued += a.max_iters;
         // exchange epochs run on from launch to launch (a tag of an earlier launch never equals a later epoch), so the area is
         // zeroed only when it is new, after a failed launch, and before the 32-bit epoch would wrap
-        if ((unsigned long long)t->cl_epoch + (unsigned)a.max_iters + 4ull >= 0xffffffffull) {
+        if ((unsigned long long)t->cl_epoch + (unsigned)a.max_iters + 6ull >= 0xffffffffull) {
             TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
             t->cl_epoch = 0;
         }
         a.epoch0 = t->cl_epoch;
-        t->cl_epoch += ((unsigned)a.max_iters + 3u) & ~1u;   // even: the parity of an epoch picks the half of the area
+        t->cl_epoch += ((unsigned)a.max_iters + 5u) & ~1u;   // even: the parity of an epoch picks the half of the area (+1: the arrival rendezvous)
         hipError_t e = hipSuccess;
         TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
-        if (e != hipSuccess) { tsp::set_last_error("k_cluster_two_opt launch", e, __FILE__, __LINE__); return TSP_DEV_E_HIP; }
+        if (e != hipSuccess) {
+            // the attribute or the launch was refused (an LDS size this device does not grant): nothing ran, the tours in
+            // HBM are as they were -- the caller may go on with another engine
+            tsp::set_last_error("k_cluster_two_opt launch", e, __FILE__, __LINE__);
+            (void)hipGetLastError();
+            if (fell_through && launches_done == 0) *fell_through = 1;
+            return TSP_DEV_E_HIP;
+        }
         TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState) * (size_t)B, hipMemcpyDeviceToHost, s));
         if (!t->h_cl_err) TSP_HIP_TRY(hipHostMalloc(&t->h_cl_err, sizeof(int)));
         TSP_HIP_TRY(hipMemcpyAsync(t->h_cl_err, a.err, sizeof(int), hipMemcpyDeviceToHost, s));   // pinned: no staging copy
@@ -1324,15 +1357,32 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         if (err) {
             (void)hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s);   // the error word too
             t->cl_epoch = 0;
+            {   // remember it: the next AUTO decisions on this device leave the CLUSTER engine out (64 calls, doubling up to 4096
+                // with every further give-up), so that a driver making thousands of calls on a shared device stalls once
+                tsp_dev_ctx *cx = inst->ctx;
+                cx->cl_giveups += 1;
+                cx->cl_backoff = std::min(4096, std::max(64, 2 * cx->cl_backoff));
+                cx->cl_skip = cx->cl_backoff;
+            }
+            if (tabu) {
+                // the failed launch may have consumed or added to the side words of the tabu-list accounting: back to what
+                // they were after the last launch that completed (zero before the first)
+                if (launches_done > 0) (void)hipMemcpyAsync(tabu->d_tabu_pairs, tabu->d_tabu_pairs + 4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+                else (void)hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s);
+            }
             tsp::set_last_error("k_cluster_two_opt: a workgroup of the cluster was not resident (exchange gave up)",
                                 hipErrorLaunchFailure, __FILE__, __LINE__);
             if (fell_through) *fell_through = 1;
             return TSP_DEV_E_HIP;
         }
+        launches_done += 1;
+        inst->ctx->cl_backoff = 0;
         bool done = true;
         for (int b = 0; b < B; ++b) done = done && t->h_state[b].done;
         if (done) { if (all_done) *all_done = 1; break; }
         if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
+        // another launch follows: keep the tabu-list side words as they stand after this one (see the give-up path)
+        if (tabu) TSP_HIP_TRY(hipMemcpyAsync(tabu->d_tabu_pairs + 4, tabu->d_tabu_pairs, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }
     bool unfinished = status == TSP_TIME_LIMIT_EXCEEDED;
     for (int b = 0; b < B; ++b) unfinished = unfinished || !t->h_state[b].done;

@@ -155,7 +155,6 @@ dim3 scan_grid(const tsp_dev_tours *t) {
     return dim3(gx, gy, t->B);
 }
 
-int env_int(const char *name, int dflt);
 
 // BEST sweeps of this handle go through k_move_recs + k_sweep (no tabu list, metric with the new-edge bound)
 bool sorted_sweep_possible(const tsp_dev_tours *t) {
@@ -333,10 +332,6 @@ double wall_s() {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 }  // namespace
 
@@ -353,7 +348,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         bool usable = false;
         const int rc = tabu_list_prepare(t, tabu, &usable);
         if (rc) return rc;
-        t->tabu_list_run = usable && env_int("TSP_TABU_DENSE", 0) == 0;
+        t->tabu_list_run = usable && TSP_SW(t->inst, TABU_DENSE, 0) == 0;
         tabu->last_run_list = t->tabu_list_run;
         if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
     }
@@ -449,8 +444,15 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode);
 int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int sync, int *all_done) {
     struct PlanGuard { tsp_dev_tours *t; ~PlanGuard() { t->cl_tabu_plan = false; } } plan_guard{t};
     t->cl_tabu_plan = tabu && iter >= 0 && tenure >= 0;   // the cluster's sorted scan at any size (see cl_plan)
-    if (tabu && iter >= 0 && tenure >= 0 && t->B == 1 && env_int("TSP_TABU_DENSE", 0) == 0 && env_int("TSP_ENGINE", 0) != 1 &&
-        tsp_cluster_fits(t, TSP_2OPT_BEST) && tsp_cluster_sorted(t, TSP_2OPT_BEST)) {
+    // after a give-up (a workgroup was not resident) the CLUSTER engine is left out for a while: tsp_dev_ctx::cl_skip
+    auto cluster_allowed = [&]() {
+        tsp_dev_ctx *cx = t->inst->ctx;
+        if (TSP_SW(t->inst, ENGINE, 0) == 3 || cx->cl_skip <= 0) return true;
+        --cx->cl_skip;
+        return false;
+    };
+    if (tabu && iter >= 0 && tenure >= 0 && t->B == 1 && TSP_SW(t->inst, TABU_DENSE, 0) == 0 && TSP_SW(t->inst, ENGINE, 0) != 1 &&
+        tsp_cluster_fits(t, TSP_2OPT_BEST) && tsp_cluster_sorted(t, TSP_2OPT_BEST) && cluster_allowed()) {
         bool usable = false;
         int rc = tabu_list_prepare(t, tabu, &usable);
         if (rc) return rc;
@@ -469,11 +471,17 @@ int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, dou
                 if (sync == 1) TSP_HIP_TRY(hipStreamSynchronize(s));
                 return status;
             }
-            // a workgroup was not resident: the tour in HBM is untouched (stamps it cleared stay cleared: the same
-            // clears are due again), the same descent goes through the GRID engine
+            // A workgroup was not resident.  The tour and the control block in HBM are as the last launch that COMPLETED left
+            // them (a run of more than 4096 sweeps, or a time-limited one, is several launches), the side words of the list
+            // accounting have been put back to that point too (tsp_cluster_run), and stamps the failed launch cleared stay
+            // cleared (expired either way: the same decisions, the same clears are due again).  The skipped pairs of the
+            // completed launches come off the evaluation count now -- tsp_grid_run starts its own count at zero -- and the
+            // rest of the descent goes through the GRID engine.
+            hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, s, t->d_state, tabu->d_tabu_pairs);
+            TSP_HIP_TRY(hipGetLastError());
         }
     }
-    if ((!tabu || iter < 0 || tenure < 0) && t->B == 1 && env_int("TSP_ENGINE", 0) != 1 && tsp_cluster_fits(t, TSP_2OPT_BEST)) {
+    if ((!tabu || iter < 0 || tenure < 0) && t->B == 1 && TSP_SW(t->inst, ENGINE, 0) != 1 && tsp_cluster_fits(t, TSP_2OPT_BEST) && cluster_allowed()) {
         // no list (check_tenure answers 0 before it reads anything, tabusearch.c:84): the plain best-improvement descent
         hipStream_t s = t->inst->ctx->stream;
         int fell = 0;
@@ -650,10 +658,10 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     const long long pairs_budget = 2000000;
     int auto_min = (int)std::min<long long>(32, std::max<long long>(4, pairs_budget / ((long long)B * inst->n)));
     auto_min = auto_min >= 32 ? 32 : (auto_min >= 16 ? 16 : (auto_min >= 8 ? 8 : 4));
-    t->first_min_rows = std::max(1, env_int("TSP_FIRST_MIN_ROWS", auto_min));
+    t->first_min_rows = std::max(1, TSP_SW(inst, FIRST_MIN_ROWS, auto_min));
     t->first_rows_per_block =
-        std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_FIRST_ROWS_PER_BLOCK", std::min(8, t->first_min_rows))));
-    t->first_max_rows = std::max(t->first_min_rows, env_int("TSP_FIRST_MAX_ROWS", 2048));
+        std::min(kMaxRowsPerBlock, std::max(1, TSP_SW(inst, FIRST_ROWS_PER_BLOCK, std::min(8, t->first_min_rows))));
+    t->first_max_rows = std::max(t->first_min_rows, TSP_SW(inst, FIRST_MAX_ROWS, 2048));
     {   // Every launch dispatches the grid of the LARGEST chunk (blocks beyond a tour's current chunk
         // return at once, but dispatching them is not free): with many tours keep that grid near
         // 16k blocks so that a step stays latency-sized.
@@ -664,23 +672,23 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     }
     {   // k_first: a fixed grid of gy tile rows (<= 64: a block numbers the working blocks with one wave); a block
         // takes ceil(chunk / gy) <= kMaxRowsPerBlock rows.  Many tours: keep the launch near 16k blocks.
-        t->first_rj = env_int("TSP_FIRST_RJ", 2) == 2 ? 2 : 1;
+        t->first_rj = TSP_SW(inst, FIRST_RJ, 2) == 2 ? 2 : 1;
         const long long gx = (inst->n + kScanThreads * t->first_rj - 1) / (kScanThreads * t->first_rj);
         // every working block takes a ticket on one word (~12 ns each): few, fat blocks
-        const int gy = (int)std::max<long long>(1, std::min<long long>(env_int("TSP_FIRST_GRID_ROWS", 8), 16384 / (gx * B)));
+        const int gy = (int)std::max<long long>(1, std::min<long long>(TSP_SW(inst, FIRST_GRID_ROWS, 8), 16384 / (gx * B)));
         t->first_grid_rows = std::min(64, gy);
-        t->first_max_rows2 = std::max(t->first_min_rows, std::min(env_int("TSP_FIRST_MAX_ROWS", 2048), t->first_grid_rows * kMaxRowsPerBlock));
-        t->first_v1 = env_int("TSP_FIRST_V1", 0);
+        t->first_max_rows2 = std::max(t->first_min_rows, std::min(TSP_SW(inst, FIRST_MAX_ROWS, 2048), t->first_grid_rows * kMaxRowsPerBlock));
+        t->first_v1 = TSP_SW(inst, FIRST_V1, 0);
     }
-    t->best_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, env_int("TSP_BEST_ROWS_PER_BLOCK", 32)));
-    t->count_evals = env_int("TSP_COUNT_EVALS", 1);
-    t->use_graph = env_int("TSP_USE_GRAPH", 0);
+    t->best_rows_per_block = std::min(kMaxRowsPerBlock, std::max(1, TSP_SW(inst, BEST_ROWS_PER_BLOCK, 32)));
+    t->count_evals = TSP_SW(inst, COUNT_EVALS, 1);
+    t->use_graph = TSP_SW(inst, USE_GRAPH, 0);
     const size_t bn = (size_t)B * inst->n;
     const dim3 gb = scan_grid<TSP_2OPT_BEST>(t), gf = scan_grid<TSP_2OPT_FIRST>(t);
     t->partial_per_tour = std::max((size_t)gb.x * gb.y, (size_t)gf.x * gf.y);
     t->partial_per_tour = std::max(t->partial_per_tour, (size_t)((inst->n + kScanThreads - 1) / kScanThreads) * t->first_grid_rows);
-    t->sorted_min_n = env_int("TSP_SORTED_MIN_N", 1000);
-    t->cl_sorted_min_n = env_int("TSP_SORTED_MIN_N", 8);
+    t->sorted_min_n = TSP_SW(inst, SORTED_MIN_N, 1000);
+    t->cl_sorted_min_n = TSP_SW(inst, SORTED_MIN_N, 8);
     size_t rec_per_tour = (size_t)inst->n;
     size_t cl_words = (size_t)B * 64 * 64;   // k_first: one arrival counter per tour x tile row, 64 ints apart
     if (inst->d_sperm) {
@@ -688,13 +696,13 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         // per CU for one tour (measured over n = 500 .. 15 000: 256 blocks are best below ~4000 nodes, 512-768 above)
         const long long gp = (long long)inst->ng * (inst->ng + 1) / 2;
         const int one_tour = (int)std::min<long long>(768, std::max<long long>(256, gp / 8));
-        const int want = env_int("TSP_SWEEP_BLOCKS", std::max(16, one_tour / B));
+        const int want = TSP_SW(inst, SWEEP_BLOCKS, std::max(16, one_tour / B));
         t->sweep_blocks = std::max(1, want / kSweepCluster) * kSweepCluster;
         rec_per_tour = std::max(rec_per_tour, (size_t)inst->n_slots);
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->sweep_blocks);
         cl_words = std::max(cl_words, (size_t)B * (t->sweep_blocks / kSweepCluster) * 64);
         const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
-        if (npairs <= (1ll << 24) && inst->ng <= 32768 && env_int("TSP_SWEEP_TABLE", 1)) {
+        if (npairs <= (1ll << 24) && inst->ng <= 32768 && TSP_SW(inst, SWEEP_TABLE, 1)) {
             // group pairs by box distance, dealt to the clusters in turn (see k_sweep)
             const int ng = inst->ng, Q = t->sweep_blocks / kSweepCluster;
             const long long ntests = (npairs + Q - 1) / Q;
@@ -727,7 +735,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
     TSP_HIP_TRY(hipMalloc(&t->d_partial, (size_t)B * t->partial_per_tour * sizeof(Partial)));
     TSP_HIP_TRY(hipMalloc(&t->d_slot_evals, (size_t)B * t->partial_per_tour * sizeof(int)));
     TSP_HIP_TRY(hipMalloc(&t->d_ticket, (size_t)B * sizeof(int)));
-    t->use_recs = env_int("TSP_BEST_RECS", 1);
+    t->use_recs = TSP_SW(inst, BEST_RECS, 1);
     TSP_HIP_TRY(hipMalloc(&t->d_rec, (size_t)B * rec_per_tour * sizeof(NodeRec)));
     t->max_tile_rows = std::max((int)gb.y, (int)gf.y);
     TSP_HIP_TRY(hipMalloc(&t->d_row_ticket, (size_t)B * t->max_tile_rows * sizeof(int)));
@@ -907,6 +915,9 @@ int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed) {
 
 int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out) {
     if (!inst || !out) return TSP_DEV_E_ARG;
+    // the stamp of pair (i, j) sits at the int index x_udir_pos(i, j, n) (src/utility.c:17-30), here and in every kernel:
+    // n (n - 1) / 2 must stay below 2^31 (n <= 65 536, the limit the reference's int arithmetic has too)
+    if ((long long)inst->n * (inst->n - 1) / 2 >= (1ll << 31)) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(inst->ctx->device));
     tsp_dev_tabu *tb = new tsp_dev_tabu();
     tb->inst = inst;
@@ -917,10 +928,10 @@ int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out) {
     tb->list_cap = (int)std::max<long long>(16, std::min<long long>(tb->count, 1ll << 18));
     TSP_HIP_TRY(hipMalloc(&tb->d_list, sizeof(int2) * (size_t)tb->list_cap));
     TSP_HIP_TRY(hipMalloc(&tb->d_list_n, sizeof(int)));
-    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, 4 * sizeof(unsigned long long)));
+    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, 8 * sizeof(unsigned long long)));   // 4 side words + their snapshot (CLUSTER engine, multi-launch runs)
     TSP_HIP_TRY(hipHostMalloc(&tb->h_list_n, sizeof(int)));
     TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), inst->ctx->stream));
-    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), inst->ctx->stream));
+    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, 8 * sizeof(unsigned long long), inst->ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(inst->ctx->stream));
     tb->list_valid = true;   // no stamp is set: the empty list is complete
     tb->list_ub = 0; tb->list_compact_at = 2048;

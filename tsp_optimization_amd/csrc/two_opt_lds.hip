@@ -536,10 +536,6 @@ double wall_s() {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 template <int WT, bool INT, int MODE, bool CACHE>
 hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
@@ -554,7 +550,7 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
         granted = bytes;
     }
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, env_int("TSP_LDS_PROBE", 65536), env_int("TSP_LDS_PROBE2", 1));
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, TSP_SW(t->inst, LDS_PROBE, 65536), TSP_SW(t->inst, LDS_PROBE2, 1));
     return hipGetLastError();
 }
 
@@ -563,7 +559,7 @@ hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_it
     // integer-coordinate variants: integer edge lengths < 2^21, exact as floats
     constexpr bool CAN_CACHE = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
     if constexpr (CAN_CACHE) {
-        if (lds_bytes_needed(t->n, true) <= (size_t)160 * 1024 && env_int("TSP_LDS_EDGE_CACHE", 1))
+        if (lds_bytes_needed(t->n, true) <= (size_t)t->inst->ctx->lds_bytes && TSP_SW(t->inst, LDS_EDGE_CACHE, 1))
             return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, true>(t, rmin, rmax, max_iters)
                                           : launch_lds_k<WT, INT, TSP_2OPT_BEST, true>(t, rmin, rmax, max_iters);
     }
@@ -591,7 +587,7 @@ extern "C" int tsp_dev_debug_lds_scan(unsigned long long *out8) {
 #endif
 
 bool tsp_lds_fits(const tsp_dev_inst *inst) {
-    return inst && inst->n <= 65535 && lds_bytes_needed(inst->n) <= (size_t)160 * 1024;
+    return inst && inst->n <= 65535 && lds_bytes_needed(inst->n) <= (size_t)inst->ctx->lds_bytes;
 }
 
 // Runs the tours of `t` to their local optima with the LDS engine (launches of bounded length so
@@ -602,7 +598,7 @@ int tsp_lds_run(tsp_dev_tours *t, int mode, double time_limit_s, int *all_done) 
     const double t0 = wall_s();
     // smallest chunk ~4000 pairs (measured: att532 best at 8 rows, rand5000 at 1-2 rows)
     const int auto_rmin = std::max(1, std::min(16, (4000 + t->n / 2) / t->n));
-    const int rmin = std::max(1, std::min(kLdsRows, env_int("TSP_LDS_MIN_ROWS", auto_rmin)));
+    const int rmin = std::max(1, std::min(kLdsRows, TSP_SW(t->inst, LDS_MIN_ROWS, auto_rmin)));
     const int rmax = kLdsRows;
     const int max_iters = mode == TSP_2OPT_FIRST ? 8192 : 256;
     if (all_done) *all_done = 0;

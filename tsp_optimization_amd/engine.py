@@ -53,6 +53,7 @@ def lib():
         L.tsp_dev_inst_destroy.argtypes = [vp]
         L.tsp_dev_inst_destroy.restype = None
         L.tsp_dev_inst_size.argtypes = [vp]
+        L.tsp_dev_inst_reload_switches.argtypes = [vp]
         L.tsp_dev_dist_pairs.argtypes = [vp, ip, ip, C.c_int, dp]
         L.tsp_dev_selftest_raw_sqrt.argtypes = [vp, dp, C.c_int, dp]
         L.tsp_dev_dist_matrix.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_float)]
@@ -105,7 +106,7 @@ def lib():
 
 EXPORTED = [
     "tsp_dev_open", "tsp_dev_close", "tsp_dev_last_error", "tsp_dev_count", "tsp_dev_synchronize",
-    "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size",
+    "tsp_dev_stream", "tsp_dev_inst_create", "tsp_dev_inst_destroy", "tsp_dev_inst_size", "tsp_dev_inst_reload_switches",
     "tsp_dev_dist_pairs", "tsp_dev_selftest_raw_sqrt", "tsp_dev_dist_matrix", "tsp_dev_construct", "tsp_dev_extramileage", "tsp_dev_two_opt",
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
@@ -187,6 +188,10 @@ class Instance:
         if self._h:
             lib().tsp_dev_inst_destroy(self._h)
             self._h = C.c_void_p()
+
+    def reload_switches(self):
+        """Re-read the TSP_* environment switches for this instance (they are read once, at creation)."""
+        _check(lib().tsp_dev_inst_reload_switches(self._h))
 
     def __enter__(self):
         return self

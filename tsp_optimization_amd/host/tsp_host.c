@@ -39,12 +39,14 @@ static tsp_dev_comm *g_comm = NULL;   /* one process per GPU: this process's ran
 /* CLI extensions of this build (-starts, -gpus): instance_params is the reference's struct and takes no new fields */
 static int g_cli_starts = 256, g_cli_gpus = 0;
 static cache_slot g_cache[CACHE_SLOTS];
-/* device copy of the skip_edge array a caller keeps passing to alg_2opt_tabu (see there) */
-static struct { int *host; tsp_dev_inst *dev; tsp_dev_tabu *tb; size_t bytes; int registered; } g_tabu_cache;
+/* The device-side stamp array alg_2opt_tabu works on, kept from call to call (one per device instance: 4 n (n-1) / 2 bytes of
+ * HBM are not allocated and freed per call).  It holds no host state: every call uploads the caller's skip_edge array and
+ * downloads it again, and nothing of the caller's memory is page-locked or remembered -- the reference's tabu() CALLOCs
+ * and FREEs that array per run (tabusearch.c:195, :318), and a later allocation may well get the same address. */
+static struct { tsp_dev_inst *dev; tsp_dev_tabu *tb; } g_tabu_cache;
 
 static void tabu_cache_drop(void) {
     if (g_tabu_cache.tb) tsp_dev_tabu_destroy(g_tabu_cache.tb);
-    if (g_tabu_cache.registered) (void)tsp_dev_host_unregister(g_tabu_cache.host);
     memset(&g_tabu_cache, 0, sizeof g_tabu_cache);
 }
 
@@ -76,7 +78,7 @@ static double nodes_checksum(const point *p, int n) {
 
 /* Device copy of inst->nodes (uploaded on first use, then reused while the host array is unchanged). */
 static tsp_dev_inst *dev_inst_locked(instance *inst) {
-    if (!inst->nodes || inst->num_nodes < 4) LOG_E("instance has no nodes (or fewer than 4)");
+    if (!inst->nodes || inst->num_nodes < 3) LOG_E("instance has no nodes (or fewer than 3)");
     const double sum = nodes_checksum(inst->nodes, inst->num_nodes);
     const int ic = inst->params.integer_cost ? 1 : 0;
     int victim = 0;
@@ -328,10 +330,10 @@ int alg_2opt(instance *inst) {
 }
 
 /* src/tabusearch.c:107-178.  skip_edge is the caller's host array of n(n-1)/2 stamps, which the caller also writes
- * between two calls (tabu() stamps two edges per iteration, check_tenure clears lazily), so it has to travel to the device
- * and back around every call.  What a loop like the reference's tabu() does not pay again and again: the device copy (one
- * handle per skip_edge pointer, kept until another pointer or instance comes) and pageable-memory copies (the array is
- * page-locked once).  A driver that wants no copies at all keeps the stamps resident: tsp_host_tabu / HEU_Tabu_* below. */
+ * between two calls (tabu() stamps two edges per iteration, check_tenure clears lazily), so it travels to the device
+ * and back around every call (2 x 200 MB at n = 10 000).  What a loop like the reference's tabu() does not pay again and
+ * again is the device allocation.  A driver that wants no copies at all keeps the stamps resident: tsp_host_tabu /
+ * HEU_Tabu_* below. */
 int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int iter, const int tenure) {
     tsp_two_opt_stats st;
     memset(&st, 0, sizeof st);
@@ -341,14 +343,10 @@ int alg_2opt_tabu(instance *inst, int *skip_edge, int *stored_prev, const int it
     tsp_dev_tabu *tb = NULL;
     int rc = 0;
     if (skip_edge) {
-        if (g_tabu_cache.tb && (g_tabu_cache.host != skip_edge || g_tabu_cache.dev != d)) tabu_cache_drop();
+        if (g_tabu_cache.tb && g_tabu_cache.dev != d) tabu_cache_drop();
         if (!g_tabu_cache.tb) {
             rc = tsp_dev_tabu_create(d, &g_tabu_cache.tb);
-            if (!rc) {
-                g_tabu_cache.host = skip_edge; g_tabu_cache.dev = d;
-                g_tabu_cache.bytes = sizeof(int) * (size_t)inst->num_nodes * (size_t)(inst->num_nodes - 1) / 2;
-                g_tabu_cache.registered = tsp_dev_host_register(skip_edge, g_tabu_cache.bytes) == 0;   /* best effort */
-            }
+            if (!rc) g_tabu_cache.dev = d;
         }
         tb = g_tabu_cache.tb;
         if (!rc) rc = tsp_dev_tabu_upload(tb, skip_edge);
