@@ -141,7 +141,10 @@ void export_tour(instance *inst);
  * inst->solution (ties -> lowest start).  rank/world shard the starts (k % world == rank). */
 int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost,
                               int *best_start);
-/* world > 1 (one process per GPU, device LOCAL_RANK): the ranks agree on the winner with one RCCL all-reduce(min) of
+/* One rank's share of it and nothing else: the starts k % world == rank, the shard's best in inst->solution (no communication). */
+int tsp_host_multistart_shard(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start);
+/* HEU_2opt_grasp_multistart with world > 1 is COLLECTIVE (one process per GPU, device LOCAL_RANK; every rank must call it):
+ * after its shard the ranks agree on the winner with one RCCL all-reduce(min) of
  * (true cost << 24 | start) and one broadcast of its tour (tsp_dev_multistart_* of include/tsp_hip.h); the RCCL id travels
  * from rank 0 through the file TSP_RCCL_ID_FILE.  The same job in ONE process on devices 0 .. gpus-1 (one thread per GPU,
  * ncclCommInitAll, grouped collectives); shard_seconds[gpus] (may be NULL) receives every GPU's construct + 2-opt time. */

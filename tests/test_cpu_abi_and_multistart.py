@@ -45,7 +45,7 @@ def test_libtsp_host_exports_the_reference_entry_points(built):
               "alg_2opt", "alg_2opt_tabu", "HEU_2opt_grasp", "HEU_2opt_grasp_iter", "HEU_2opt_greedy",
               "HEU_2opt_greedy_iter", "reverse_path", "copy_instance", "rand_choice", "x_udir_pos",
               "get_elapsed_time", "free_instance", "TSP_heuc", "parse_comand_line", "parse_instance",
-              "export_tour", "fitness_batch", "HEU_2opt_grasp_multistart", "tsp_host_multistart_gpus",
+              "export_tour", "fitness_batch", "HEU_2opt_grasp_multistart", "tsp_host_multistart_gpus", "tsp_host_multistart_shard",
               "tsp_host_last_stats", "tsp_host_shutdown"]:
         assert hasattr(L, n), n
 

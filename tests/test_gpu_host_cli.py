@@ -61,6 +61,7 @@ def host():
     L.fitness_batch.argtypes = [C.POINTER(Instance), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double)]
     L.HEU_2opt_grasp_multistart.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.tsp_host_multistart_shard.argtypes = L.HEU_2opt_grasp_multistart.argtypes
     L.tsp_host_last_stats.argtypes = [C.POINTER(C.c_longlong)] * 3 + [C.POINTER(C.c_double)]
     L.kick.argtypes = [C.POINTER(Instance)]
     L.tsp_host_vns.argtypes = [C.POINTER(Instance), C.c_longlong]
@@ -200,7 +201,10 @@ def test_multistart_256_matches_golden_table_and_shards(host):
         h = HostInstance("att532")
         O.srandom(123)
         cost, start = C.c_double(), C.c_int()
-        assert host.HEU_2opt_grasp_multistart(C.byref(h.c), 256, rank, world, C.byref(cost), C.byref(start)) == 0
+        # world 1: the whole job; world 2: one rank's shard alone (with world > 1 HEU_2opt_grasp_multistart is collective: it
+        # would wait for the other rank's RCCL rendezvous -- tests/test_gpu_multigpu.py drives that path)
+        fn = host.HEU_2opt_grasp_multistart if world == 1 else host.tsp_host_multistart_shard
+        assert fn(C.byref(h.c), 256, rank, world, C.byref(cost), C.byref(start)) == 0
         mine = [r for r in table if r["k"] % world == rank]
         best = min(mine, key=lambda r: (r["opt_true"], r["k"]))
         assert (cost.value, start.value) == (best["opt_true"], best["k"])

@@ -836,11 +836,9 @@ static tsp_dev_comm *comm_locked(int rank, int world) {
     return g_comm;
 }
 
-/* BASELINE config 4: `starts` GRASP starts (stream order of heuristics.c:519, :127), alg_2opt on each, best TRUE cost.
- * world == 1: this process refines every start.  world > 1 (one process per GPU): this rank refines the starts
- * k % world == rank on its device, then the ranks run the all-reduce(min) + broadcast over RCCL, so that EVERY rank
- * returns the global winner in inst->solution, *best_true_cost and *best_start. */
-int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+/* One rank's share of BASELINE config 4, no communication: `starts` GRASP starts (stream order of heuristics.c:519, :127), the
+ * starts k % world == rank refined by alg_2opt on this process's device, the shard's best TRUE cost / start / tour. */
+int tsp_host_multistart_shard(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
     const int n = inst->num_nodes;
     if (starts < 1 || world < 1 || rank < 0 || rank >= world) return -1;
     int *node, *gid;
@@ -853,6 +851,26 @@ int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, d
     int rc = refine_shard(dev_inst_locked(inst), n, mine, node, gid, u, limit_of(inst), &best, &best_k, best_succ);
     pthread_mutex_unlock(&g_lock);
     if (rc < 0) dev_fail("multistart", rc);
+    if (best_k >= 0) {
+        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = best_succ[v]; }
+        inst->solution.obj_best = best;
+    }
+    if (best_true_cost) *best_true_cost = best;
+    if (best_start) *best_start = best_k;
+    free(node); free(gid); free(u); free(best_succ);
+    return 0;
+}
+
+/* BASELINE config 4 end to end.  world == 1: this process refines every start.  world > 1 (one process per GPU, COLLECTIVE:
+ * every rank must call it): this rank refines its shard on its device, then the ranks run the all-reduce(min) of
+ * (true cost << 24 | start) + the broadcast of the winner's tour over RCCL, so that EVERY rank returns the global winner in
+ * inst->solution, *best_true_cost and *best_start. */
+int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+    const int n = inst->num_nodes;
+    double best = DBL_MAX;
+    int best_k = -1;
+    int rc = tsp_host_multistart_shard(inst, starts, rank, world, &best, &best_k);
+    if (rc) return rc;
     const char *force = getenv("TSP_FORCE_COMM");   /* tests: run the collectives with a single rank too */
     if (world > 1 || (force && *force == '1')) {
         int64_t mine_packed = NO_RESULT_PACKED, win = 0;
@@ -863,18 +881,14 @@ int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, d
         rc = tsp_dev_multistart_allreduce(cm, mine_packed, &win);
         if (!rc && win != NO_RESULT_PACKED) {
             best = (double)(win >> 24); best_k = (int)(win & 0xffffff);
-            rc = tsp_dev_multistart_bcast_tour(cm, best_k % world, best_succ, 1, n);
+            rc = tsp_dev_multistart_bcast_tour(cm, best_k % world, &inst->solution.edges[0].j, 2, n);   /* in place, stride 2 */
         }
         pthread_mutex_unlock(&g_lock);
         if (rc) LOG_E("multi-start collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
-    }
-    if (best_k >= 0) {
-        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = best_succ[v]; }
-        inst->solution.obj_best = best;
+        if (best_k >= 0) { stamp_edge_sources(inst); inst->solution.obj_best = best; }
     }
     if (best_true_cost) *best_true_cost = best;
     if (best_start) *best_start = best_k;
-    free(node); free(gid); free(u); free(best_succ);
     return 0;
 }
 
