@@ -62,6 +62,84 @@ def test_cluster_sizes_match_oracle(eng, ctx, monkeypatch, C, mode, sorted_scan,
     assert _same(st, est), (st, est)
 
 
+@pytest.mark.parametrize("C", [1, 3, 8, 64, 256])
+@pytest.mark.parametrize("fs_rows", [0, 1, 40, None])   # never the box-pruned step / nearly always / mixed / the default
+@pytest.mark.parametrize("name,ic", [("pr299", 1), ("att532", 1), ("d493", 0), ("d493", 1), ("rand1000", 1), ("dsj1000", 1)])
+def test_first_improvement_on_the_sorted_replica_matches_oracle(eng, ctx, monkeypatch, C, fs_rows, name, ic):
+    """alg_2opt (heuristics.c:438-502) with the replica in Hilbert-rank order: the probe and the tiles scan read it through the id
+    maps, and a step whose last hits lay `fs_rows` rows apart takes the box-pruned scan with key = the first improving pair after
+    the cursor.  Whatever the mix of step kinds and the cluster size, the trajectory is the reference's: final tour, cost,
+    sweeps, evaluations, moves, reversal length."""
+    monkeypatch.setenv("TSP_CLUSTER_BLOCKS", str(C))
+    monkeypatch.setenv("TSP_CLUSTER_FIRST_SORTED", "8")
+    if fs_rows is not None:
+        monkeypatch.setenv("TSP_CLUSTER_FS_ROWS", str(fs_rows))
+    xy, wt = load_instance(name)
+    inst = eng.Instance(ctx, xy, wt, ic)
+    _, succ0, obj0 = O.greedy(xy, wt, integer_cost=ic)
+    rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.FIRST, engine=eng.ENGINE_CLUSTER)
+    es, eo, est = _oracle(xy, wt, succ0, obj0, 0, ic)
+    assert rc == 0 and (s == es).all() and o == eo, (o, eo)
+    assert _same(st, est), (st, est)
+    if C in (3, 64):   # and from a random tour (dense phase first: probe, tiles, then the sparse tail)
+        rng = np.random.default_rng(C)
+        t0 = random_tour(len(xy), rng)
+        c0 = O.succ_cost(xy, wt, t0, integer_cost=ic)
+        rc, s, o, st = inst.two_opt(t0, c0, mode=eng.FIRST, engine=eng.ENGINE_CLUSTER)
+        es, eo, est = _oracle(xy, wt, t0, c0, 0, ic)
+        assert rc == 0 and (s == es).all() and o == eo and _same(st, est), (st, est)
+    inst.close()
+
+
+def test_first_improvement_sorted_replica_batches_ties_and_resident_calls(eng, ctx, monkeypatch):
+    """Batches on lattices (exactly tied deltas; a first-improvement step takes the FIRST pair in (i<j) order, never the best),
+    sizes around group edges, and a resident tour that is called again at its local optimum (one sweep that finds nothing:
+    the box-pruned step) and after a perturbation (the running mean of the rows between hits carries over)."""
+    monkeypatch.setenv("TSP_CLUSTER_FIRST_SORTED", "8")
+    monkeypatch.setenv("TSP_CLUSTER_FS_ROWS", "2")
+    rng = np.random.default_rng(77)
+    for C in (2, 7, 16):
+        monkeypatch.setenv("TSP_CLUSTER_BLOCKS", str(C))
+        for n, hi in ((9, 50), (64, 9), (65, 3000), (129, 12), (300, 3000), (513, 40), (700, 25)):
+            xy = rng.integers(0, hi, size=(n, 2)).astype(np.float64)
+            inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+            succ0 = np.stack([random_tour(n, rng) for _ in range(3)])
+            obj0 = np.array([O.succ_cost(xy, O.EUC_2D, t) for t in succ0])
+            rc, s, o, st = inst.two_opt(succ0, obj0, mode=eng.FIRST, engine=eng.ENGINE_CLUSTER)
+            for b in range(3):
+                es, eo, est = _oracle(xy, O.EUC_2D, succ0[b], obj0[b], 0, 1)
+                assert (s[b] == es).all() and o[b] == eo and _same(st[b], est), (C, n, b, st[b], est)
+            inst.close()
+    monkeypatch.setenv("TSP_CLUSTER_BLOCKS", "64")
+    xy, wt = load_instance("pr1002")
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ0, obj0)
+    rc, obj = tours.two_opt(eng.FIRST, engine=eng.ENGINE_CLUSTER)
+    _, es, eo, est, _ = O.two_opt_first(xy, wt, succ0, obj0)
+    s, o, st = tours.download()
+    assert (s[0] == es).all() and obj[0] == eo and _same(st[0], est)
+    rc, obj = tours.two_opt(eng.FIRST, engine=eng.ENGINE_CLUSTER)          # at the optimum: one sweep, nothing found
+    s2, o2, st2 = tours.download()
+    assert (s2[0] == es).all() and obj[0] == eo and st2[0]["sweeps"] == est["sweeps"] + 1 and st2[0]["moves"] == est["moves"]
+    assert st2[0]["evals"] - st[0]["evals"] == len(xy) * (len(xy) - 1) // 2 - len(xy)
+    p1, p2, p3 = 100, 400, 800
+    kicked_obj = tours.vns_kick(p1, p2, p3)                                # vns.c:11-100, then alg_2opt on the resident tour
+    ks, ko = O.vns_kick_positions(xy, wt, es, p1, p2, p3) if hasattr(O, "vns_kick_positions") else (None, None)
+    rc, obj = tours.two_opt(eng.FIRST, engine=eng.ENGINE_CLUSTER)
+    s3, o3, st3 = tours.download()
+    if ks is not None:
+        _, e3, eo3, est3, _ = O.two_opt_first(xy, wt, ks, ko)
+        assert kicked_obj == ko and (s3[0] == e3).all() and obj[0] == eo3
+    else:
+        assert O.is_tour(s3[0]) and O.succ_cost(xy, wt, s3[0]) == obj[0]
+        _, e3, eo3, _, _ = O.two_opt_first(xy, wt, s3[0], obj[0])
+        assert (e3 == s3[0]).all()                                         # a local optimum of alg_2opt
+    tours.close()
+    inst.close()
+
+
 def test_best_improvement_batch_larger_than_the_chip(eng, ctx):
     """300 tours of berlin52, best improvement, the engine the library picks (CLUSTER, one workgroup per tour, no exchange, more
     workgroups than CUs: they run in turns) against the oracle, tour by tour."""

@@ -234,9 +234,14 @@ def test_vns_kick_matches_oracle(host):
         assert (h.succ == es).all() and h.obj == eo and O.is_tour(h.succ)
 
 
-@pytest.mark.parametrize("name,rounds", [("pr299", 40), ("att532", 12)])
-def test_vns_rounds_match_oracle(host, name, rounds):
-    """HEU_VNS with the round cap: same incumbent tour and cost as the oracle's restatement of vns.c:103-166."""
+@pytest.mark.parametrize("name,rounds,fs", [("pr299", 40, None), ("att532", 12, None), ("pr299", 40, 2), ("pr1002", 10, 30)])
+def test_vns_rounds_match_oracle(host, monkeypatch, name, rounds, fs):
+    """HEU_VNS with the round cap: same incumbent tour and cost as the oracle's restatement of vns.c:103-166.
+    fs: alg_2opt on the replica in rank order with the box-pruned first-improvement step (what n >= 2000 gets by default) from
+    `fs` rows between hits on -- every round ends with sweeps that find nothing, the case that step is for."""
+    if fs is not None:
+        monkeypatch.setenv("TSP_CLUSTER_FIRST_SORTED", "8")
+        monkeypatch.setenv("TSP_CLUSTER_FS_ROWS", str(fs))
     h = HostInstance(name)
     h.c.params.time_limit = 600
     O.srandom(123)

@@ -19,7 +19,7 @@ def run(seed, cases, ctx=None, verbose=True, max_n=3000):
     finally:
         if prev is None: os.environ.pop("TSP_SORTED_MIN_N", None)
         else: os.environ["TSP_SORTED_MIN_N"] = prev
-        for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE"): os.environ.pop(k, None)
+        for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE", "TSP_CLUSTER_FIRST_SORTED", "TSP_CLUSTER_FS_ROWS"): os.environ.pop(k, None)
 
 
 def _run(seed, cases, ctx, verbose, max_n):
@@ -63,6 +63,10 @@ def _run(seed, cases, ctx, verbose, max_n):
         ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
         # the same two descents on the CLUSTER engine with a random number of workgroups per tour
         os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 8, 17, 64, 200, 256])))
+        # first improvement: the plain replica, or the one in rank order with the box-pruned step never / always / now and then
+        fs = int(rng.choice([-1, 0, 1, 3, 60]))
+        os.environ["TSP_CLUSTER_FIRST_SORTED"] = "0" if fs < 0 else "8"
+        os.environ["TSP_CLUSTER_FS_ROWS"] = str(max(fs, 0))
         inst.reload_switches()
         if n <= 300:
             rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)

@@ -39,6 +39,9 @@ struct alignas(16) TourState {
     // pairs a lane evaluated a bound or the delta for, pairs that reached tier 1, delta expressions executed, node
     // records derived for the sorted scan
     long long lane_pairs, tier1_pairs, exact_pairs, staged_recs;
+    // FIRST on the CLUSTER engine: running mean of the rows between two hits (decides between the tiles scan and the
+    // box-pruned scan of a step; survives k_rearm, so that a driver's next call starts with what the last one learnt)
+    int hit_rows, pad0, pad1, pad2;
 };
 
 constexpr int kScanThreads = 256;
@@ -54,7 +57,7 @@ constexpr int kApplyThreads = 1024;
     X(LDS_PROBE) X(LDS_PROBE2) X(LDS_MIN_ROWS) X(LDS_EDGE_CACHE) X(NO_ICOORD) X(NO_FILTER) X(NO_PRUNE) X(SORTED_MIN_N)      \
     X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
     X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \
-    X(CONSTRUCT_NN) X(LDS_PAIR)
+    X(CONSTRUCT_NN) X(LDS_PAIR) X(CLUSTER_FS_ROWS)
 namespace tsp {
 enum SwitchId {
 #define TSP_SW_ENUM(name) SW_##name,

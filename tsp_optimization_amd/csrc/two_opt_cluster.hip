@@ -22,6 +22,11 @@
 //           four at a time through an fp32 tier 0, and the pairs that survive it are queued per wave and taken
 //           through tiers 1 and 2 sixty-four at a time.  Group bound: gmax2[g] = longest tour edge INCIDENT to a
 //           node of g (either direction), which a move changes for at most four groups -- no O(n) rebuild per step.
+//   FIRST on the sorted replica (round 3): a first-improvement step whose last hits lay hundreds of rows apart -- the tail of
+//           every descent, the sweeps that find (almost) nothing, HEU_VNS's last sweeps of a round -- takes the sorted scan
+//           too, with key = the first improving pair after the cursor (min pair index among delta < 0; bound 0 in the box
+//           test): ONE step decides the whole rest of the sweep (a tiles sweep over all rows of rand10000 that finds nothing
+//           costs 217 us).  Dense phases keep the probe and the tiles scan, which then read the replica through the id maps.
 // Residency: the cluster protocol needs all B C workgroups on the chip at once; the host launches at most one per CU
 // and every spin is bounded (a workgroup that gives up raises `err`, everybody leaves, the host falls back to GRID).
 #include "two_opt_common.hpp"
@@ -80,6 +85,7 @@ struct ClusterArgs {
     int tabu_list_cap, iter, tenure;
     unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
+    int fs_rows;            // FIRST on the sorted replica: a step takes the box-pruned scan when the running mean of the rows between hits is at least this
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up ...
     unsigned long long spin_ticks;   // ... or this much time (100 MHz ticks) without the peers' tags, whichever comes first
@@ -145,7 +151,7 @@ struct ClLayout {
     size_t coord, order, pos, gbox, gmax, stage, list, items, queue, rows, scratch, total;
 };
 constexpr int kClMaxStagePairs = 8;
-__host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted, int stage_pairs) {
+__host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted, int stage_pairs, bool tiles_too = false) {
     ClLayout L;
     size_t o = 0;
     L.coord = o; o = cl_align16(o + coord_elem * (size_t)nid);
@@ -160,6 +166,7 @@ __host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coo
         L.list = o; o = cl_align16(o + sizeof(int) * kClListCap);
         L.items = o; o = cl_align16(o + sizeof(unsigned short) * 64 * (size_t)stage_pairs);
         L.queue = o; o = cl_align16(o + sizeof(unsigned) * kClQueue * kClWaves);
+        if (tiles_too) { L.rows = o; o = cl_align16(o + sizeof(NodeRec) * kClRows); }   // first improvement: both scans
     } else {
         L.rows = o; o = cl_align16(o + sizeof(NodeRec) * kClRows);
     }
@@ -315,9 +322,10 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
 // none of it (as run-time branches on a pointer the list code cost the plain sweep 2.5 %: 11.3 -> 11.6 us at n = 10 000)
 template <int WT, bool INT, int MODE, typename CT, bool SORTED, bool TABU = false>
 __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArgs a) {
-    static_assert(!TABU || SORTED, "tabu lists ride on the sorted scan");
-    static_assert(!SORTED || (MODE == TSP_2OPT_BEST && has_root_filter<WT>()), "the sorted scan is a best-improvement sweep on a sqrt metric");
+    static_assert(!TABU || (SORTED && MODE == TSP_2OPT_BEST), "tabu lists ride on the sorted best-improvement scan");
+    static_assert(!SORTED || has_root_filter<WT>(), "the sorted scan needs the new-edge bound of a sqrt metric");
     constexpr bool BEST = MODE == TSP_2OPT_BEST;
+    constexpr bool FS = SORTED && !BEST;   // first improvement on the sorted replica: internal ids = Hilbert ranks, caller ids through a.gid / a.iid
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
     // bounded integer distances (< 2^21): a delta is an integer below 2^23 in magnitude and travels as an int32
     constexpr bool kSmallD = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tour = (int)blockIdx.x / C, c = (int)blockIdx.x % C;
     using SR = ClStage<CT>;
-    const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED, a.stage_pairs);
+    const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED, a.stage_pairs, FS);
     CT *coord = reinterpret_cast<CT *>(smem + L.coord);
     idx_t *order = reinterpret_cast<idx_t *>(smem + L.order);
     idx_t *pos = reinterpret_cast<idx_t *>(smem + L.pos);
@@ -386,6 +394,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     }
     if (tid == 0) *s_fail = 0;
     int ci = st->ci, cj = st->cj, chunk = min(max(st->chunk_rows, 1), a.rmax), done = 0;
+    int hit_rows = st->hit_rows;   // FIRST: running mean of the rows between hits (kept from call to call: HEU_VNS's rounds look alike)
+    // caller's node id <-> id inside the replica (the same thing unless the replica is in rank order)
+    auto to_int = [&](int v) -> int { if constexpr (SORTED) return a.iid[v]; else return v; };
+    auto to_ext = [&](int v) -> int { if constexpr (SORTED) return a.gid[v]; else return v; };
     double obj = st->obj, seen = st->seen_cost;
     long long sweeps = st->sweeps, evals = st->evals, moves = st->moves, reversed = st->reversed,
               scanned = st->pairs_scanned, steps = st->steps;
@@ -464,20 +476,22 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 const bool act = j < n && i < n - 1;
                 bool hit = false, adjp = false;
                 double delta = 0.0;
+                unsigned pip = 0;
                 if (act) {
-                    const NodeRec ri = cl_node<WT, INT, CT>(coord, order, pos, n, i);
-                    const NodeRec rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
-                    adjp = j == ri.succ || rj.succ == i;   // heuristics.c:471
+                    const NodeRec ri = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(i));
+                    const NodeRec rj = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(j));
+                    adjp = rj.id == ri.succ || rj.succ == ri.id;   // heuristics.c:471
                     if (!adjp) {
                         delta = pair_delta<WT, INT>(ri, rj);
                         hit = delta < 0;
                     }
+                    pip = ((unsigned)ri.id << 16) | (unsigned)rj.id;
                 }
                 w_lane += __popcll(__ballot(act));
                 w_ex += __popcll(__ballot(act && !adjp));
                 const unsigned long long hb = __ballot(hit), ab = __ballot(adjp);
                 if (lane == 0) { s_k[wave] = hb; s_ll[wave] = (long long)ab; }
-                if (hb && lane == __builtin_ctzll(hb)) { s_d[wave] = delta; s_k[8 + wave] = make_key(i, j); }
+                if (hb && lane == __builtin_ctzll(hb)) { s_d[wave] = delta; s_k[8 + wave] = make_key(i, j); s_ip[wave] = pip; }
                 int ei = ci, ej = cj + kClThreads;   // the last thread's pair: where the scan goes on after a probe without a hit
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
@@ -504,15 +518,22 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
                         const unsigned khi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(kw >> 32), fw);
                         key = ((u64)khi << 32) | klo;
-                        ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
+                        ipair = (unsigned)__builtin_amdgcn_readlane((int)s_ip[lw], fw);   // the pair inside the replica
                     }
                 }
                 if (!probe_hit) { si = ei; sj = ej; __syncthreads(); }   // the vote's scratch is rewritten by the arg-min below
             }
             row_lo = si; row_hi = min(si + chunk, n - 1);
         }
+        // which scan this step takes (the same answer in every workgroup: it depends on replicated state alone)
+        bool do_sorted = SORTED && BEST;
+        if constexpr (FS) {
+            do_sorted = a.fs_rows > 0 && hit_rows >= a.fs_rows && !probe_hit;
+            if (do_sorted) row_hi = n - 1;   // the box-pruned scan decides the whole rest of the sweep
+        }
+        const u64 startkey = make_key(si, sj);   // FIRST on the sorted replica: pairs up to here are behind the cursor
 
-        if constexpr (SORTED) {
+        if constexpr (SORTED) if (do_sorted) {
             // ---- sorted scan: box tests on this workgroup's share of the group pairs, then the survivors ------
             const int *tab = a.pairtab + (size_t)c * a.ntests;
             const int P = a.stage_pairs;
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 // tier 1, both new edges, no root: |ab| + |a1 b1| < T2 = bound + d(a,a1) + d(b,b1) + margin
                                 //   <=>  w = T2^2 - s1 - s2 > 0 and 4 s1 s2 < w^2   (bound: this lane's best so far)
                                 const double dx1 = ri.x - rj.x, dy1 = ri.y - rj.y;
-                                const double dx = ri.xs - rj.xs, dy = ri.ys - rj.ys, T2 = ri.ds + bd + rj.ds + a.sum_margin;
+                                const double dx = ri.xs - rj.xs, dy = ri.ys - rj.ys, T2 = ri.ds + (BEST ? bd : 0.0) + rj.ds + a.sum_margin;
                                 const double sc = ATT10 ? 0.1 : 1.0;
                                 const double p1 = sc * fma(dx1, dx1, dy1 * dy1), p2 = sc * fma(dx, dx, dy * dy);
                                 const double w = T2 * T2 - p1 - p2;
@@ -616,10 +637,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                         gi = a.gid[ri.id]; gj = a.gid[rj.id];
                                         delta = gi < gj ? pair_delta<WT, INT>(ri, rj) : pair_delta<WT, INT>(rj, ri);
                                     }
-                                    if (delta < bd || (delta == bd && delta < 0.0)) {
+                                    if (BEST ? (delta < bd || (delta == bd && delta < 0.0)) : (delta < 0.0)) {
                                         if constexpr (INT) { if (a.dbg & 8) { gi = ri.id; gj = rj.id; } else { gi = a.gid[ri.id]; gj = a.gid[rj.id]; } }
                                         const u64 kk = make_key(min(gi, gj), max(gi, gj));
-                                        if (delta < bd || kk < key) {
+                                        // best improvement: arg-min of (delta, pair); first improvement: the first improving pair after the cursor
+                                        if (BEST ? (delta < bd || kk < key) : (kk > startkey && kk < key)) {
                                             bool is_tabu = false;
                                             if constexpr (TABU) {   // tabusearch.c:137-149 on node ids, a = the lower one, lazy clears included
                                                 const bool lo = gi < gj;
@@ -672,7 +694,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                     SR::xydf(stage[ridx[qq]], rx[qq], ry[qq], rd[qq]);
                                     SR::xydf(stage[cidx[qq]], cxf[qq], cyf[qq], cdf[qq]);
                                 }
-                                const float bf = (float)(bd + prune2 + 2.0);
+                                const float bf = (float)((BEST ? bd : 0.0) + prune2 + 2.0);
 #pragma unroll
                                 for (int qq = 0; qq < RU; ++qq) {
                                     const float dx = rx[qq] - cxf[qq], dy = ry[qq] - cyf[qq], T = rd[qq] + cdf[qq] + bf;
@@ -687,7 +709,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                 }
 #pragma unroll
                                 for (int qq = 0; qq < RU; ++qq) {
-                                    const double dx = rx[qq] - cx[qq], dy = ry[qq] - cy[qq], T = rd[qq] + cd[qq] + bd + prune2;
+                                    const double dx = rx[qq] - cx[qq], dy = ry[qq] - cy[qq], T = rd[qq] + cd[qq] + (BEST ? bd : 0.0) + prune2;
                                     need[qq] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);
                                 }
                             }
@@ -711,7 +733,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     __syncthreads();   // the stage (and, after the last chunk, the list) is rewritten next
                 }
             }
-        } else {
+        }
+        if constexpr (!SORTED || FS) if (!do_sorted) {
             // ---- tiles: rpt rows x 512 columns, tile t = row block * nb + column batch, dealt round-robin.  A step costs
             // the latency of its slowest workgroup, so the rows per tile shrink until every workgroup of the cluster has a
             // tile (a first-improvement step right after a move scans a few dozen rows: 20 tiles of 32 rows would leave
@@ -736,13 +759,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 __syncthreads();
                 constexpr bool F32T0 = std::is_same<CT, float2>::value && has_root_filter<WT>();
                 if (tid < nr) {
-                    const NodeRec rr = cl_node<WT, INT, CT>(coord, order, pos, n, rb + tid);
+                    const NodeRec rr = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(rb + tid));
                     s_rows[tid] = rr;
                     if constexpr (F32T0) s_rowsf[tid] = make_float4((float)rr.x, (float)rr.y, (float)rr.ds, 0.f);
                 }
                 NodeRec rj;
                 const bool act = j < n && j > rb;
-                if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, j);
+                if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(j));
                 __syncthreads();
                 CL_T(9);
 #ifdef TSP_STAMPS
@@ -781,7 +804,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             const NodeRec ri = s_rows[r0 + u];
                             const u64 kq = make_key(i, j);
                             if (need[u]) {
-                                ok = j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                                ok = j > i && rj.id != ri.succ && rj.succ != ri.id;   // heuristics.c:471 / tabusearch.c:134
                                 if constexpr (!BEST) ok = ok && (i > si || j > sj) && kq < key;
                                 const double bound = BEST ? bd : 0.0;
                                 ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + prune2);
@@ -794,9 +817,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             if (ok) {
                                 const double delta = pair_delta<WT, INT>(ri, rj);
                                 if constexpr (!BEST) {
-                                    if (delta < 0) { bd = delta; key = kq; }
+                                    if (delta < 0) { bd = delta; key = kq; ipair = ((unsigned)ri.id << 16) | (unsigned)rj.id; }
                                 } else {
-                                    if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                                    if (better(delta, kq, bd, key)) { bd = delta; key = kq; ipair = ((unsigned)ri.id << 16) | (unsigned)rj.id; }
                                 }
                             }
                         }
@@ -805,7 +828,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     for (int r = 0; r < nr; ++r) {
                         const int i = rb + r;
                         const NodeRec ri = s_rows[r];
-                        bool ok = act && j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                        bool ok = act && j > i && rj.id != ri.succ && rj.succ != ri.id;   // heuristics.c:471 / tabusearch.c:134
                         if constexpr (!BEST) ok = ok && (i > si || j > sj);
                         const u64 kq = make_key(i, j);
                         if constexpr (!BEST) ok = ok && kq < key;
@@ -822,9 +845,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         if (ok) {
                             const double delta = pair_delta<WT, INT>(ri, rj);
                             if constexpr (!BEST) {
-                                if (delta < 0) { bd = delta; key = kq; }
+                                if (delta < 0) { bd = delta; key = kq; ipair = ((unsigned)ri.id << 16) | (unsigned)rj.id; }
                             } else {
-                                if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                                if (better(delta, kq, bd, key)) { bd = delta; key = kq; ipair = ((unsigned)ri.id << 16) | (unsigned)rj.id; }
                             }
                         }
                     }
@@ -834,7 +857,6 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     if (!any_hit && __syncthreads_or(key != kNoKey)) { any_hit = true; hit_rb = rbi; }
                 }
             }
-            if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key);
         }
 
         CL_T(1);
@@ -842,7 +864,6 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
         // winners through LDS to the first wave, which reduces them, runs the exchange and hands the result back
         if (!probe_hit) {
-            if constexpr (!SORTED) { if (key != kNoKey) ipair = ((unsigned)key_i(key) << 16) | (unsigned)key_j(key); }
             const u64 mykey = key;
             wave_argmin<BEST>(bd, key);
             const unsigned long long owners = __ballot(mykey == key && key != kNoKey);
@@ -935,11 +956,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         }
         CL_T(3);
         const bool found = key != kNoKey && (!BEST || bd < 0);
-        const int wi = found ? (int)(ipair >> 16) : -1, wj = found ? (int)(ipair & 0xffffu) : -1;   // internal ids
+        const int wi = found ? (int)(ipair >> 16) : -1, wj = found ? (int)(ipair & 0xffffu) : -1;   // ids inside the replica
+        const int fi = found ? key_i(key) : -1, fj = found ? key_j(key) : -1;                       // the caller's ids of the same pair
 
         // ---- reference-equivalent evaluation count (FIRST; kept by the cluster's first workgroup) ----------------
         long long adj = 0;
-        int ni = wi, nj = wj;
+        int ni = fi, nj = fj;
         if constexpr (!BEST) {
             if (!found) { ni = row_hi - 1; nj = n - 1; }
             if (probe_hit) adj = probe_adj;   // counted by the probe's ballots
@@ -947,8 +969,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
                 long long cnt = 0;
                 for (int r = ci + tid; r <= ni; r += kClThreads) {
-                    const int p = pos[r];
-                    const int s = order[p + 1 == n ? 0 : p + 1], q = order[p == 0 ? n - 1 : p - 1];
+                    const int p = pos[to_int(r)];
+                    const int s = to_ext(order[p + 1 == n ? 0 : p + 1]), q = to_ext(order[p == 0 ? n - 1 : p - 1]);
                     const u64 ks = make_key(r, s), kq = make_key(r, q);
                     cnt += (s > r && ks > lo && ks <= hi) ? 1 : 0;
                     cnt += (q > r && kq > lo && kq <= hi) ? 1 : 0;
@@ -1033,9 +1055,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 moves += 1; reversed += Lr - 1;
                 // the next chunk: twice the rows this hit was away from the cursor -- dense phases (a random tour: a hit
                 // in almost every row) scan a row or two per step, sparse ones keep the chunk that found something
-                chunk = max(a.rmin, min(a.rcap, 2 * (wi - ci + 1)));
-                ci = wi; cj = wj;
+                chunk = max(a.rmin, min(a.rcap, 2 * (fi - ci + 1)));
+                hit_rows = (3 * hit_rows + (fi - ci) + 2) >> 2;   // running mean of the rows between hits
+                ci = fi; cj = fj;
             } else {
+                hit_rows = max(hit_rows, row_hi - ci);  // nothing within these rows: the next hit is at least that far
                 chunk = min(chunk * 2, a.rmax);
                 if (row_hi >= n - 1) {                  // sweep complete
                     sweeps += 1;
@@ -1092,6 +1116,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     }
     if (tid == 0) {
         st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
+        st->hit_rows = hit_rows;
         st->sweeps = sweeps; st->evals = evals; st->moves = moves; st->reversed = reversed;
         st->pairs_scanned = scanned; st->steps = steps;
         st->parity = 0; st->pending = 0;
@@ -1133,13 +1158,16 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     p.float_coords = wt == WT_EUC_2D_ICOORD || wt == WT_CEIL_2D_ICOORD || wt == WT_ATT_ICOORD;
     // (runs with a tabu list take the sorted scan at any size: their list code rides on it, and the alternative reads four
     // stamps per pair -- two_opt_tabu_list.hpp)
-    p.sorted = mode == TSP_2OPT_BEST && inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
-               (inst->n >= t->cl_sorted_min_n || (t->cl_tabu_plan && inst->n >= 8));
+    p.sorted = inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
+               (mode == TSP_2OPT_BEST ? (inst->n >= t->cl_sorted_min_n || (t->cl_tabu_plan && inst->n >= 8))
+                                      // first improvement: the replica in rank order pays from a few thousand nodes on (its tiles steps
+                                      // read through the id maps; what it buys is the box-pruned step for sparse phases)
+                                      : (TSP_SW(inst, CLUSTER_FIRST_SORTED, 2000) > 0 && inst->n >= TSP_SW(inst, CLUSTER_FIRST_SORTED, 2000)));
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
     const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs
     for (p.stage_pairs = p.sorted ? kClMaxStagePairs : 0;; --p.stage_pairs) {
-        p.lds = cl_layout(inst->n, p.nid, inst->ng, ce, p.sorted, p.stage_pairs).total;
+        p.lds = cl_layout(inst->n, p.nid, inst->ng, ce, p.sorted, p.stage_pairs, p.sorted && mode == TSP_2OPT_FIRST).total;
         p.ok = p.lds <= cl_lds_limit(inst->ctx);
         if (p.ok || p.stage_pairs <= 1) break;
     }
@@ -1164,7 +1192,12 @@ hipError_t cl_launch_k(tsp_dev_tours *t, const ClusterArgs &a, size_t lds) {
 template <int WT, bool INT>
 hipError_t cl_launch(tsp_dev_tours *t, int mode, const ClPlan &p, const ClusterArgs &a) {
     using CT = std::conditional_t<cl_float_coords<WT>(), float2, double2>;
-    if (mode == TSP_2OPT_FIRST) return cl_launch_k<WT, INT, TSP_2OPT_FIRST, CT, false>(t, a, p.lds);
+    if (mode == TSP_2OPT_FIRST) {
+        if constexpr (has_root_filter<WT>()) {
+            if (p.sorted) return cl_launch_k<WT, INT, TSP_2OPT_FIRST, CT, true>(t, a, p.lds);
+        }
+        return cl_launch_k<WT, INT, TSP_2OPT_FIRST, CT, false>(t, a, p.lds);
+    }
     if constexpr (has_root_filter<WT>()) {
         if (p.sorted && a.tabu) return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, true, true>(t, a, p.lds);
         if (p.sorted) return cl_launch_k<WT, INT, TSP_2OPT_BEST, CT, true>(t, a, p.lds);
@@ -1203,7 +1236,8 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode) {
     if (p.sorted) {   // no more workgroups than a few group pairs each
         const long long npairs = (long long)t->inst->ng * (t->inst->ng + 1) / 2;
         C = (int)std::max<long long>(1, std::min<long long>(C, (npairs + 3) / 4));
-    } else {
+    }
+    if (!p.sorted || mode == TSP_2OPT_FIRST) {
         const long long nb = (t->n + kClThreads - 1) / kClThreads, nrb = (t->n - 1 + kClRows - 1) / kClRows;
         C = (int)std::max<long long>(1, std::min<long long>(C, nb * nrb));
         // first improvement: a step scans a few dozen rows, and the exchange gets slower with every workgroup that takes part
@@ -1300,6 +1334,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu_side = tabu->d_tabu_pairs;
     }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
+    a.fs_rows = std::max(0, TSP_SW(inst, CLUSTER_FS_ROWS, 320));
     a.dbg = TSP_SW(inst, CLUSTER_DEBUG, 0);
     a.stage_pairs = p.stage_pairs;
     a.spin_limit = (unsigned)std::max(16, TSP_SW(inst, CLUSTER_SPIN_LIMIT, (int)kClSpinLimit));
