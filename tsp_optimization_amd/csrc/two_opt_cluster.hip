@@ -86,6 +86,8 @@ struct ClusterArgs {
     unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int fs_rows;            // FIRST on the sorted replica: a step takes the box-pruned scan when the running mean of the rows between hits is at least this
+    int fs_exit;            // FIRST, plain replica: the launch ends when that mean reaches this (the host goes on with the rank-order variant); 0 = never
+    int fs_leave;           // FIRST, rank-order replica: the launch ends when the mean falls below this (back to the plain variant); 0 = never
     int stage_pairs;        // sorted: group pairs whose records are staged in LDS at a time
     unsigned spin_limit;    // sweeps of the exchange area before a workgroup gives up ...
     unsigned long long spin_ticks;   // ... or this much time (100 MHz ticks) without the peers' tags, whichever comes first
@@ -417,7 +419,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (lane == 0) gmax[g] = m;
         }
     };
-    if constexpr (SORTED) {
+    // first improvement on the rank-order replica: the group bounds are only read by a box-pruned step; moves made by tiles /
+    // probe steps leave them stale (gmax_dirty) and the next box-pruned step rebuilds them all
+    bool gmax_dirty = FS;
+    if constexpr (SORTED && BEST) {
         group_bounds(wave, kClWaves, ng);
         __syncthreads();
     }
@@ -454,7 +459,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (*s_fail) failed = true;
         }
     }
-    for (int iter = 0; iter < a.max_iters && !done && !failed; ++iter) {
+    bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
+    for (int iter = 0; iter < a.max_iters && !done && !failed && !leave; ++iter) {
         int row_lo = 0, row_hi = n - 1;
         double bd = 0.0;
         u64 key = kNoKey;
@@ -534,6 +540,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         const u64 startkey = make_key(si, sj);   // FIRST on the sorted replica: pairs up to here are behind the cursor
 
         if constexpr (SORTED) if (do_sorted) {
+            if constexpr (FS) {
+                if (gmax_dirty) {   // wave-uniform, the same in every workgroup
+                    group_bounds(wave, kClWaves, ng);
+                    gmax_dirty = false;
+                    __syncthreads();
+                }
+            }
             // ---- sorted scan: box tests on this workgroup's share of the group pairs, then the survivors ------
             const int *tab = a.pairtab + (size_t)c * a.ntests;
             const int P = a.stage_pairs;
@@ -999,7 +1012,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 order[p] = w; order[q] = u;
                 pos[w] = (idx_t)p; pos[u] = (idx_t)q;
             }
-            if constexpr (SORTED) {
+            if constexpr (FS) { if (!do_sorted) gmax_dirty = true; }
+            if constexpr (SORTED) if (!gmax_dirty) {
                 __syncthreads();
                 // the move changes the incident edges of a, succ a, b, succ b only: their groups' bounds are rebuilt
                 if (a.dbg & 1) {
@@ -1067,6 +1081,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     else { seen = obj; ci = 0; cj = 0; }
                 } else { ci = row_hi - 1; cj = n - 1; }
             }
+            if constexpr (FS) leave = !done && a.fs_leave > 0 && hit_rows < a.fs_leave;
+            else leave = !done && a.fs_exit > 0 && hit_rows >= a.fs_exit;
         }
     }
 
@@ -1150,7 +1166,8 @@ struct ClPlan {
 };
 
 // Which scan a run in `mode` uses on this handle, and whether the replica fits in LDS.
-ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
+// want_fs: first improvement on the rank-order replica (the variant a sparse phase of a single tour's descent is handed to)
+ClPlan cl_plan(const tsp_dev_tours *t, int mode, bool want_fs = false) {
     ClPlan p;
     const tsp_dev_inst *inst = t->inst;
     if (inst->n > 65534) return p;
@@ -1160,9 +1177,9 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode) {
     // stamps per pair -- two_opt_tabu_list.hpp)
     p.sorted = inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
                (mode == TSP_2OPT_BEST ? (inst->n >= t->cl_sorted_min_n || (t->cl_tabu_plan && inst->n >= 8))
-                                      // first improvement: the replica in rank order pays from a few thousand nodes on (its tiles steps
-                                      // read through the id maps; what it buys is the box-pruned step for sparse phases)
-                                      : (TSP_SW(inst, CLUSTER_FIRST_SORTED, 2000) > 0 && inst->n >= TSP_SW(inst, CLUSTER_FIRST_SORTED, 2000)));
+                                      // first improvement: sparse phases of larger instances (a sweep of the tiles scan that
+                                      // finds nothing is 217 us at n = 10 000, 92 us at n = 1 002; a box-pruned step 12 us)
+                                      : (want_fs && TSP_SW(inst, CLUSTER_FIRST_SORTED, 800) > 0 && inst->n >= TSP_SW(inst, CLUSTER_FIRST_SORTED, 800)));
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
     const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs
@@ -1237,7 +1254,7 @@ int tsp_cluster_size(const tsp_dev_tours *t, int mode) {
         const long long npairs = (long long)t->inst->ng * (t->inst->ng + 1) / 2;
         C = (int)std::max<long long>(1, std::min<long long>(C, (npairs + 3) / 4));
     }
-    if (!p.sorted || mode == TSP_2OPT_FIRST) {
+    if (!p.sorted) {
         const long long nb = (t->n + kClThreads - 1) / kClThreads, nrb = (t->n - 1 + kClRows - 1) / kClRows;
         C = (int)std::max<long long>(1, std::min<long long>(C, nb * nrb));
         // first improvement: a step scans a few dozen rows, and the exchange gets slower with every workgroup that takes part
@@ -1264,12 +1281,24 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     // all workgroups must be resident (TSP_CLUSTER_ALLOW_OVERSUB=1 lifts the check: the tests use it to drive the give-up path)
     if (C > 1 && (long long)B * C > std::max(1, inst->ctx->num_cus) && !TSP_SW(inst, CLUSTER_ALLOW_OVERSUB, 0)) return TSP_DEV_E_ARG;
 
+    // First improvement of a single tour: two variants of the kernel hand the descent to each other between launches -- the plain
+    // replica (probe + tiles at full speed) while hits come close together, the replica in rank order with the box-pruned step
+    // once the running mean of the rows between hits (TourState::hit_rows, kept by both) passes fs_rows, back below fs_rows / 4.
+    ClPlan pf;   // the rank-order variant's plan
+    bool fs_avail = false;
+    const int fs_rows = std::max(0, TSP_SW(inst, CLUSTER_FS_ROWS, 320));
+    if (mode == TSP_2OPT_FIRST && B == 1 && fs_rows > 0 && max_steps < 0) {
+        pf = cl_plan(t, mode, /*want_fs=*/true);
+        const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
+        fs_avail = pf.ok && pf.sorted && C <= (npairs + 3) / 4;
+    }
     // per-instance tables of the sorted scan: coordinates in rank order (padding far away), node -> rank
-    if (p.sorted && !inst->d_rcoord) {
-        std::vector<double2> rc((size_t)p.nid);
+    if ((p.sorted || fs_avail) && !inst->d_rcoord) {
+        const int nid_sorted = inst->ng * 64;
+        std::vector<double2> rc((size_t)nid_sorted);
         std::vector<int> sperm((size_t)inst->n_slots);
         TSP_HIP_TRY(hipMemcpy(sperm.data(), inst->d_sperm, sizeof(int) * sperm.size(), hipMemcpyDeviceToHost));
-        for (int k = 0; k < p.nid; ++k) {
+        for (int k = 0; k < nid_sorted; ++k) {
             const int v = sperm[k];
             rc[k] = v >= 0 ? make_double2(inst->h_xy[2 * (size_t)v], inst->h_xy[2 * (size_t)v + 1]) : make_double2(1e30, 1e30);
         }
@@ -1290,7 +1319,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         t->cl_epoch = 0;
         t->cl_C = C;
     }
-    if (p.sorted && !t->d_cl_pairtab) {
+    if ((p.sorted || fs_avail) && !t->d_cl_pairtab) {
         const int ng = inst->ng;
         const long long npairs = (long long)ng * (ng + 1) / 2;
         const long long ntests = (npairs + C - 1) / C;
@@ -1311,10 +1340,15 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     }
 
     ClusterArgs a;
-    a.coord = p.sorted ? inst->d_rcoord : inst->d_coord;
+    auto set_plan = [&](const ClPlan &q) {   // what depends on the numbering of the replica
+        a.coord = q.sorted ? inst->d_rcoord : inst->d_coord;
+        a.gid = q.sorted ? inst->d_sperm : nullptr;
+        a.iid = q.sorted ? inst->d_sinv : nullptr;
+        a.nid = q.nid;
+        a.stage_pairs = q.stage_pairs;
+    };
+    set_plan(p);
     a.orders = t->d_order; a.states = t->d_state;
-    a.gid = p.sorted ? inst->d_sperm : nullptr;
-    a.iid = p.sorted ? inst->d_sinv : nullptr;
     a.gbox = inst->d_gbox;
     a.pairtab = t->d_cl_pairtab;
     a.slots = t->d_cl_slots;
@@ -1325,7 +1359,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     }
     a.stats_part = t->d_cl_stats;
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
-    a.n = n; a.nid = p.nid; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
+    a.n = n; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
     a.count_evals = t->count_evals;
     a.tabu = nullptr; a.tabu_list = nullptr; a.tabu_list_n = nullptr; a.tabu_list_cap = 0; a.iter = iter; a.tenure = tenure; a.tabu_side = nullptr;
     if (tabu) {   // the caller has brought the handle's list up to date (tsp_tabu_list_prepare) and zeroed the side words
@@ -1334,9 +1368,10 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu_side = tabu->d_tabu_pairs;
     }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
-    a.fs_rows = std::max(0, TSP_SW(inst, CLUSTER_FS_ROWS, 320));
+    a.fs_rows = fs_rows;
+    a.fs_exit = fs_avail ? fs_rows : 0;
+    a.fs_leave = fs_avail ? std::max(1, fs_rows / 4) : 0;
     a.dbg = TSP_SW(inst, CLUSTER_DEBUG, 0);
-    a.stage_pairs = p.stage_pairs;
     a.spin_limit = (unsigned)std::max(16, TSP_SW(inst, CLUSTER_SPIN_LIMIT, (int)kClSpinLimit));
     a.spin_ticks = (unsigned long long)std::max(1, TSP_SW(inst, CLUSTER_SPIN_MS, kClSpinMs)) * 100000ull;   // 100 MHz
     a.org_x = inst->org_x; a.org_y = inst->org_y;
@@ -1359,7 +1394,16 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     int status = TSP_OK;
     int64_t queued = 0;
     int launches_done = 0;
+    bool on_fs = false;   // the variant of the launch in flight
     for (;;) {
+        if (fs_avail) {   // t->h_state: as the last launch (or the upload) left it
+            const int hr = t->h_state[0].hit_rows;
+            on_fs = on_fs ? hr >= a.fs_leave : hr >= a.fs_exit;
+            set_plan(on_fs ? pf : p);
+            // inside the rank-order variant a tiles step reads through the id maps (+1.8 us at n = 10 000) and covers ~400 rows
+            // per round of tiles: the box-pruned step takes over from half the switching distance on
+            a.fs_rows = on_fs ? std::max(1, fs_rows / 2) : fs_rows;
+        }
         a.max_iters = launch_iters;
         if (max_steps >= 0) {
             if (queued >= max_steps) break;
@@ -1375,7 +1419,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.epoch0 = t->cl_epoch;
         t->cl_epoch += ((unsigned)a.max_iters + 5u) & ~1u;   // even: the parity of an epoch picks the half of the area (+1: the arrival rendezvous)
         hipError_t e = hipSuccess;
-        TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
+        TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, on_fs ? pf : p, a); });
         if (e != hipSuccess) {
             // the attribute or the launch was refused (an LDS size this device does not grant): nothing ran, the tours in
             // HBM are as they were -- the caller may go on with another engine
