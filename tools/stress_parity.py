@@ -22,6 +22,15 @@ def run(seed, cases, ctx=None, verbose=True, max_n=3000):
         for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE", "TSP_CLUSTER_FIRST_SORTED", "TSP_CLUSTER_FS_ROWS"): os.environ.pop(k, None)
 
 
+FAILED_AT = []
+
+
+def _chk(ok, line, cond):
+    if ok and not cond:
+        FAILED_AT.append(line)      # the first check of the case that failed (a line of this file)
+    return bool(ok and cond)
+
+
 def _run(seed, cases, ctx, verbose, max_n):
     from tsp_optimization_amd import engine as E
     from helpers import random_tour
@@ -57,22 +66,22 @@ def _run(seed, cases, ctx, verbose, max_n):
         if n <= 300:   # the oracle's best-improvement descent from a random tour is O(n^3)
             rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=1)
             _, bs, bo, bst, _, _ = O.two_opt_best(xy, wt, tour, integer_cost=ic)
-            ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+            ok = _chk(ok, 60, (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"]))
         rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=1)
         _, fs, fo, fst, _ = O.two_opt_first(xy, wt, tour, cost, integer_cost=ic)
-        ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+        ok = _chk(ok, 63, (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"]))
         # the same two descents on the CLUSTER engine with a random number of workgroups per tour
         os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 3, 5, 8, 17, 64, 200, 256])))
         # first improvement: the plain replica, or the one in rank order with the box-pruned step never / always / now and then
-        fs = int(rng.choice([-1, 0, 1, 3, 60]))
-        os.environ["TSP_CLUSTER_FIRST_SORTED"] = "0" if fs < 0 else "8"
-        os.environ["TSP_CLUSTER_FS_ROWS"] = str(max(fs, 0))
+        fsr = int(rng.choice([-1, 0, 1, 3, 60]))
+        os.environ["TSP_CLUSTER_FIRST_SORTED"] = "0" if fsr < 0 else "8"
+        os.environ["TSP_CLUSTER_FS_ROWS"] = str(max(fsr, 0))
         inst.reload_switches()
         if n <= 300:
             rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)
-            ok = ok and (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"])
+            ok = _chk(ok, 73, (s == bs).all() and o == bo and (st["sweeps"], st["evals"], st["moves"]) == (bst["sweeps"], bst["evals"], bst["moves"]))
         rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
-        ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+        ok = _chk(ok, 75, (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"]))
         del os.environ["TSP_CLUSTER_BLOCKS"]
         inst.reload_switches()
         if n <= 8000:   # the LDS engine (one workgroup per tour), first improvement, with and without the probe
@@ -81,7 +90,7 @@ def _run(seed, cases, ctx, verbose, max_n):
             rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=2)
             del os.environ["TSP_LDS_PROBE"]
             inst.reload_switches()
-            ok = ok and (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"])
+            ok = _chk(ok, 84, (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"]))
         if 4 <= n <= 220:
             # alg_2opt_tabu with a dense random tabu list (live and expired stamps, tour edges included): the list path
             it, ten = int(rng.integers(2, 40)), int(rng.integers(0, 15))
@@ -95,8 +104,8 @@ def _run(seed, cases, ctx, verbose, max_n):
             tb = E.Tabu(inst)
             tb.upload(stamps)
             rc, s, o, st, _ = tb.two_opt(tour, it, ten)
-            ok = ok and (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"])
-            ok = ok and (tb.download() == exp).all() and tb.list_info()[1]
+            ok = _chk(ok, 98, (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"]))
+            ok = _chk(ok, 99, (tb.download() == exp).all() and tb.list_info()[1])
             tb.close()
         if c % 3 == 0 and n >= 8:
             # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
@@ -110,19 +119,19 @@ def _run(seed, cases, ctx, verbose, max_n):
             inst.reload_switches()
             for b in range(3):
                 _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
-                ok = ok and (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"]
-                ok = ok and (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"]
+                ok = _chk(ok, 113, (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"])
+                ok = _chk(ok, 114, (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"])
             O.srandom(1000 + c)
             ur = np.array([[O.urand() for _ in range(n)]])
             O.srandom(1000 + c)
             _, gs, go = O.grasp(xy, wt, start=s0, integer_cost=ic)
             sg, og, _ = inst.construct(E.GRASP, np.array([s0], dtype=np.int32), ur)
-            ok = ok and (sg[0] == gs).all() and og[0] == go
+            ok = _chk(ok, 120, (sg[0] == gs).all() and og[0] == go)
         inst.close()
         if verbose: print("case %d n %d wt %d ic %d %s  %.2f s" % (c, n, wt, ic, "ok" if ok else "MISMATCH", time.perf_counter() - t_case), flush=True)
         if not ok:
             bad += 1
-            print("MISMATCH case %d: n %d wt %d ic %d" % (c, n, wt, ic))
+            print("MISMATCH case %d: n %d wt %d ic %d, first failing check at stress_parity.py:%s; switches %s" % (c, n, wt, ic, FAILED_AT[-1:], {k: v for k, v in os.environ.items() if k.startswith("TSP_")}))
             break
     if own: ctx.close()
     return bad
