@@ -448,7 +448,9 @@ int tsp_dev_two_opt(tsp_dev_inst *inst, int mode, int engine, int B, int *succ, 
         // size that fits the chip, one workgroup per tour included -- tools/best_batch.py)
         // (first-improvement batches the LDS engine cannot hold -- n > ~8000 -- go to the cluster at any size: 64 tours of
         // rand10000 on 4 workgroups each 117 ms, GRID 240 ms -- tools/first_batch_big.py)
-        bool cluster = C >= 1 && (B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (C >= few || !lds_ok)));
+        // (first-improvement batches: from four workgroups per tour on the cluster is ahead of one workgroup per tour -- 64 random
+        // tours of rand5000: LDS 215 ms, 4 workgroups each 187 ms; 128 tours on 2 each 232 ms against 216 -- tools/pop_time.py)
+        bool cluster = C >= 1 && (B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (C >= std::max(1, few / 2) || !lds_ok)));
         if (cluster && force != 3 && inst->ctx->cl_skip > 0) { --inst->ctx->cl_skip; cluster = false; }   // backing off after a give-up
         if (force == 1) { lds = false; cluster = false; }
         if (force == 2 && lds_ok) { lds = true; cluster = false; }
@@ -496,7 +498,7 @@ static int run_engine_untimed(tsp_dev_tours *t, int mode, int engine, int64_t ma
     if (engine == TSP_ENGINE_CLUSTER || engine == TSP_ENGINE_AUTO) {
         const int few = std::max(1, t->inst->ctx->num_cus / 32);   // as in tsp_dev_two_opt
         bool want = engine == TSP_ENGINE_CLUSTER ||
-                    (tsp_cluster_fits(t, mode) && (t->B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (tsp_cluster_size(t, mode) >= few || !tsp_lds_fits(t->inst)))));
+                    (tsp_cluster_fits(t, mode) && (t->B < few || (mode == TSP_2OPT_BEST ? tsp_cluster_sorted(t, mode) : (tsp_cluster_size(t, mode) >= std::max(1, few / 2) || !tsp_lds_fits(t->inst)))));
         if (want && engine == TSP_ENGINE_AUTO && t->inst->ctx->cl_skip > 0) { --t->inst->ctx->cl_skip; want = false; }   // backing off after a give-up
         if (want) {
             if (!tsp_cluster_fits(t, mode)) return TSP_DEV_E_ARG;

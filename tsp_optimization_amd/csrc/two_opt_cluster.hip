@@ -1177,9 +1177,10 @@ ClPlan cl_plan(const tsp_dev_tours *t, int mode, bool want_fs = false) {
     // stamps per pair -- two_opt_tabu_list.hpp)
     p.sorted = inst->d_sperm && inst->prune_margin < 1e299 && inst->ng <= 32768 &&
                (mode == TSP_2OPT_BEST ? (inst->n >= t->cl_sorted_min_n || (t->cl_tabu_plan && inst->n >= 8))
-                                      // first improvement: sparse phases of larger instances (a sweep of the tiles scan that
-                                      // finds nothing is 217 us at n = 10 000, 92 us at n = 1 002; a box-pruned step 12 us)
-                                      : (want_fs && TSP_SW(inst, CLUSTER_FIRST_SORTED, 800) > 0 && inst->n >= TSP_SW(inst, CLUSTER_FIRST_SORTED, 800)));
+                                      // first improvement: sparse phases of larger instances (a sweep of the tiles scan that finds
+                                      // nothing is 217 us at n = 10 000; a box-pruned step 12 us).  Measured on HEU_VNS rounds
+                                      // (tools/vns_time.py): no gain at n = 1 002 / 2 000, -7 % at 5 000, -19 % at 10 000
+                                      : (want_fs && TSP_SW(inst, CLUSTER_FIRST_SORTED, 3000) > 0 && inst->n >= TSP_SW(inst, CLUSTER_FIRST_SORTED, 3000)));
     p.nid = p.sorted ? inst->ng * 64 : inst->n;
     const size_t ce = p.float_coords ? sizeof(float2) : sizeof(double2);
     // as many staged group pairs as fit (at least one), at most kClMaxStagePairs
@@ -1286,7 +1287,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     // once the running mean of the rows between hits (TourState::hit_rows, kept by both) passes fs_rows, back below fs_rows / 4.
     ClPlan pf;   // the rank-order variant's plan
     bool fs_avail = false;
-    const int fs_rows = std::max(0, TSP_SW(inst, CLUSTER_FS_ROWS, 320));
+    const int fs_rows = std::max(0, TSP_SW(inst, CLUSTER_FS_ROWS, 120));   // 80 .. 200 measure alike (rand10000: alg_2opt 20.7 ms, VNS round 3.4 ms)
     if (mode == TSP_2OPT_FIRST && B == 1 && fs_rows > 0 && max_steps < 0) {
         pf = cl_plan(t, mode, /*want_fs=*/true);
         const long long npairs = (long long)inst->ng * (inst->ng + 1) / 2;
@@ -1333,7 +1334,80 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
             }
         std::sort(pr.begin(), pr.end());
         std::vector<int> tab((size_t)C * ntests, -1);
-        for (long long k = 0; k < npairs; ++k) tab[(size_t)(k % C) * ntests + (size_t)(k / C)] = pr[(size_t)k].second;
+        bool dealt = false;
+        if (C > 1 && B == 1 && TSP_SW(inst, CLUSTER_LPT, 1)) {
+            // Deal by estimated cost instead of in turn.  A step costs the time of its slowest workgroup (1.9 us of an 11.4 us
+            // best-improvement step at n = 10 000 were spent waiting for it), and what a group pair costs is decided by the tour:
+            // whether it survives the box test and how many of its rows survive the culling.  Both are estimated here on the
+            // tour the handle holds now (Euclidean lengths: a cost model, not a decision), the survivors are dealt heaviest
+            // first to the least loaded workgroup (LPT), the others fill the tables up in turn.  Every pair is still tested in
+            // every step; only who tests it changes.
+            std::vector<int> order((size_t)n);
+            TSP_HIP_TRY(hipMemcpy(order.data(), t->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+            const double sc = (inst->wtype_public == TSP_ATT) ? 1.0 / sqrt(10.0) : 1.0;
+            auto X = [&](int v) { return inst->h_xy[2 * (size_t)v]; };
+            auto Y = [&](int v) { return inst->h_xy[2 * (size_t)v + 1]; };
+            auto len = [&](int u, int v) { return sc * sqrt((X(u) - X(v)) * (X(u) - X(v)) + (Y(u) - Y(v)) * (Y(u) - Y(v))) + 1.0; };
+            std::vector<double> ds((size_t)n, 0.0), inc((size_t)n, 0.0), gmx((size_t)ng, 0.0);
+            bool tour_ok = true;
+            for (int q = 0; q < n && tour_ok; ++q) tour_ok = order[q] >= 0 && order[q] < n;
+            if (tour_ok) {
+                for (int q = 0; q < n; ++q) {
+                    const int v = order[q], su = order[q + 1 == n ? 0 : q + 1], pv = order[q == 0 ? n - 1 : q - 1];
+                    ds[v] = len(v, su);
+                    inc[v] = std::max(ds[v], len(v, pv));
+                }
+                std::vector<int> sperm((size_t)inst->n_slots);
+                TSP_HIP_TRY(hipMemcpy(sperm.data(), inst->d_sperm, sizeof(int) * sperm.size(), hipMemcpyDeviceToHost));
+                for (int g = 0; g < ng; ++g)
+                    for (int k = 0; k < 64; ++k) { const int v = sperm[(size_t)g * 64 + k]; if (v >= 0) gmx[g] = std::max(gmx[g], inc[v]); }
+                struct Item { double cost; int e; };
+                std::vector<Item> heavy, light;
+                for (long long k = 0; k < npairs; ++k) {
+                    const int e = pr[(size_t)k].second, r = e >> 16, cg = e & 0xffff;
+                    const double T = gmx[r] + gmx[cg] + 2.0;
+                    double cost = 0.0;
+                    if (sc * sc * pr[(size_t)k].first < T * T) {
+                        const double4 &cb = inst->h_gbox[cg];
+                        int live = 0;
+                        for (int q = 0; q < 64; ++q) {
+                            const int v = sperm[(size_t)r * 64 + q];
+                            if (v < 0) continue;
+                            const double gx = std::max(0.0, std::max(cb.x - X(v), X(v) - cb.y)), gy = std::max(0.0, std::max(cb.z - Y(v), Y(v) - cb.w));
+                            const double Tr = ds[v] + gmx[cg] + 2.0;
+                            live += sc * sc * (gx * gx + gy * gy) < Tr * Tr;
+                        }
+                        cost = 8.0 + live;   // staging the pair's 128 records + its live rows against 64 columns
+                    }
+                    (cost > 0.0 ? heavy : light).push_back({cost, e});
+                }
+                std::stable_sort(heavy.begin(), heavy.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+                std::vector<double> load((size_t)C, 0.0);
+                std::vector<int> cnt((size_t)C, 0);
+                // least loaded workgroup with room: a heap keyed by load
+                std::vector<std::pair<double, int>> heap;
+                for (int w = 0; w < C; ++w) heap.push_back({0.0, w});
+                auto cmp = [](const std::pair<double, int> &x, const std::pair<double, int> &y) { return x.first > y.first || (x.first == y.first && x.second > y.second); };
+                std::make_heap(heap.begin(), heap.end(), cmp);
+                for (const Item &it : heavy) {
+                    std::pop_heap(heap.begin(), heap.end(), cmp);
+                    auto top = heap.back(); heap.pop_back();
+                    const int w = top.second;
+                    tab[(size_t)w * ntests + (size_t)cnt[w]++] = it.e;
+                    load[w] += it.cost;
+                    if (cnt[w] < ntests) { heap.push_back({load[w], w}); std::push_heap(heap.begin(), heap.end(), cmp); }
+                }
+                int w = 0;
+                for (const Item &it : light) {   // the rest in turn, wherever there is room
+                    while (cnt[w] >= ntests) w = (w + 1) % C;
+                    tab[(size_t)w * ntests + (size_t)cnt[w]++] = it.e;
+                    w = (w + 1) % C;
+                }
+                dealt = true;
+            }
+        }
+        if (!dealt)
+            for (long long k = 0; k < npairs; ++k) tab[(size_t)(k % C) * ntests + (size_t)(k / C)] = pr[(size_t)k].second;
         TSP_HIP_TRY(hipMalloc(&t->d_cl_pairtab, tab.size() * sizeof(int)));
         TSP_HIP_TRY(hipMemcpy(t->d_cl_pairtab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         t->cl_ntests = (int)ntests;
