@@ -183,6 +183,31 @@ def cpu_baselines(xy, wt, succ0, obj0, cores):
         "seconds": t2 - t0, "grasp_s": t1 - t0, "two_opt_s": t2 - t1, "cores": cores, "evals": int(sum(r[1] for r in rows)),
         "best_true_cost": rows[k][0], "best_start": k,
         "note": "the reference is single-threaded; this is an outer loop over the starts on all host cores"}
+    # configs[4] on all host cores, capped: the first 2 x cores of the 128 random individuals of rand5000 (genetic.c:349-364,
+    # seed 123), alg_2opt each (about 2 s of CPU per individual), extrapolated to the population of 128
+    from tsp_optimization_amd import multistart as MS
+    xy5 = rand_instance(5000)
+    rng = MS.LibcRandom(123)
+    sample = min(128, 2 * cores)
+    perms = [rng.random_perm(5000) for _ in range(sample)]
+    gold = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]["individuals"]
+
+    def one5(k):
+        succ = MS.perm_to_succ(perms[k])
+        c0 = O.succ_cost(xy5, O.EUC_2D, succ)
+        _, s2, o2, st, _ = O.two_opt_first(xy5, O.EUC_2D, succ, c0)
+        return o2, st["evals"], st["moves"]
+    t3 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        rows5 = list(ex.map(one5, range(sample)))
+    t4 = time.perf_counter()
+    out["config5_rand5000_population128_2opt_all_cores"] = {
+        "sample": "%d of the 128 individuals (the first ones, whole descents), %d threads" % (sample, cores),
+        "seconds_sample": t4 - t3, "seconds_extrapolated_to_128": (t4 - t3) * 128.0 / sample, "cores": cores,
+        "evals_sample": int(sum(r[1] for r in rows5)), "moves_sample": int(sum(r[2] for r in rows5)),
+        "sample_matches_golden": bool(all(int(rows5[k][0]) == int(gold[k]["cost"]) and rows5[k][1] == gold[k]["ev"] for k in range(sample))),
+        "note": "extrapolated linearly (the individuals cost alike: 1.4e8 evaluations and 40 k moves each); the reference is "
+                "single-threaded and runs mutation 3 with a 2 s limit per individual (genetic.c:432)"}
     return out
 
 
@@ -521,8 +546,54 @@ def main():
             "exhaustive": exhaustive,
         }
 
+    def first_section():
+        # the north star's named function, alg_2opt (first improvement, heuristics.c:438-502), on a resident tour: the
+        # CLUSTER engine's first-improvement kernels (the plain replica for dense phases, the replica in rank order with the
+        # box-pruned step for sparse ones; they hand the descent to each other between launches)
+        tf = E.Tours(inst, 1)
+        tf.upload(succ0[0], obj0[0])
+        ms = []
+        for r in range(4):
+            tf.reset()
+            rc, done = tf.run_engine(E.FIRST, engine=E.ENGINE_AUTO)
+            assert rc == 0 and done
+            _, of, stf = tf.download()
+            if r:
+                ms.append(stf[0]["device_ms"])
+        stf = stf[0]
+        t_nohit = []
+        for r in range(12):           # at the local optimum: the sweep that finds nothing (every descent ends with one)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            tf.two_opt(E.FIRST)
+            t_nohit.append(time.perf_counter() - t1)
+        tf.close()
+        ops = (stf["lane_pairs"] * OPS_TIER0_F32 + max(0, stf["tier1_pairs"]) * OPS_TIER1 + max(0, stf["exact_pairs"]) * OPS_EXACT +
+               max(0, stf["staged_recs"]) * OPS_STAGED)
+        kms = float(np.mean(ms))
+        out["roofline"]["first"] = {
+            "kernel": "tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, FIRST, float replica, plain | rank order>: one descent = "
+                      "a few launches (hand-overs between the two variants); device_ms = HIP events on the engine's stream around "
+                      "all of them (rocprof: profiles/r03_kernel_stats_first.csv)",
+            "bound": "valu", "device_ms": kms, "steps": int(stf["steps"]), "us_per_step": 1e3 * kms / max(1, stf["steps"]),
+            "sweeps": int(stf["sweeps"]), "reference_evals": int(stf["evals"]), "moves": int(stf["moves"]),
+            "reference_counters_match": bool((stf["sweeps"], stf["evals"], stf["moves"]) == (10, 499850987, 2704) and of[0] == 77370387),
+            "counted_lane_ops_per_descent": ops, "achieved": ops / (kms * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
+            "frac": ops / (kms * 1e-3) / FP64_LANE_OPS_PEAK, "unit": "T lane-op/s",
+            "reference_equivalent_evals_per_s": stf["evals"] / (kms * 1e-3),
+            "sweep_that_finds_nothing_us_per_call": 1e6 * float(np.mean(t_nohit[2:])),
+            "note": "a chain of 2 704 dependent moves: 6.9 us per step, 3.8 of it one all-to-all exchange (DESIGN.md 4.8)"}
+
     if rank == 0:
         guarded("roofline", roofline_section)
+        if "error" not in out.get("roofline", {"error": 1}):
+            guarded("roofline_first", first_section)
+            ex = out["roofline"].get("exhaustive") or {}
+            # the three rates the metric can mean, side by side at the top level
+            out["value_definition"] = ("lane_pairs: pairs for which a lane executed a lower bound of delta or delta itself, per second, "
+                                       "timed region, whole job")
+            out["delta_evals_per_s_exhaustive"] = ex.get("exact_delta_per_s")
+            out["reference_equivalent_pairs_per_s"] = out["evals"]["reference_equivalent_pairs_per_s"]
 
     def extras_section():
         extras = {}
@@ -554,7 +625,19 @@ def main():
                       "frac": 4 * N_NODES * N_NODES / (dm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "f64": {"kernel_ms": dm64_ms, "bytes_written": 8 * N_NODES * N_NODES,
                     "achieved": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9,
-                    "frac": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                    "frac": 8 * N_NODES * N_NODES / (dm64_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "timing": "HIP events around 12 back-to-back launches that rotate over 3 output buffers (1.2 / 2.4 GB in all): no launch "
+                      "stores into lines the 256 MB Infinity Cache may still hold"}
+        tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tj):
+            with open(tj) as f:
+                r3 = json.load(f).get("r03_dist_matrix")
+            if r3:   # rocprofv3 evidence of the same kernel (profiles/r03_*): mean duration and WRITE_SIZE per launch
+                for k in ("int32", "f64"):
+                    out["distance_matrix_build"][k].update({
+                        "rocprof_mean_us": r3[k]["rocprof_mean_us"], "write_size_bytes": r3[k]["write_size_bytes"],
+                        "hbm_frac_write_size_over_rocprof_time": r3[k]["write_size_bytes"] / (r3[k]["rocprof_mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                out["distance_matrix_build"]["rocprof"] = r3["source"]
 
     def tabu_section():
         # alg_2opt_tabu WITH a tabu list (tabusearch.c:127-165): the reference reads four stamps of the n(n-1)/2-int list
@@ -623,6 +706,16 @@ def main():
 
     if not args.no_extras:
         out["other_configs"] = sharded_configs(E, MS, ctx, rank, world, device, comm)
+        out["scaling_note"] = {
+            "timed_region": "one start per GPU, no data-path collective: weak scaling, flat by construction",
+            "sharded_configs": "configs[3] / [4] shard the starts / individuals k % world; every tour is a chain of dependent moves "
+                               "(rand5000: 40 k per individual), so more GPUs shorten the chain only by giving a tour more workgroups",
+            "expected_2opt_ms_per_rank_measured_on_one_gpu": {
+                "world": [1, 2, 4, 8],
+                "config4_att532_256_starts": [2.9, 2.9, 2.9, 2.4],
+                "config5_rand5000_128_individuals": [216, 187, 161, 149],
+                "engine": ["LDS (1 workgroup per tour)", "CLUSTER (4 per tour)", "CLUSTER (8)", "CLUSTER (16)"],
+                "source": "tools/pop_time.py, tools/shard_time.py (DESIGN.md section 5): 1.45 x on 8 GPUs for configs[4], 1.2 x for configs[3]"}}
         out["all_checks_ok"] = bool(out.get("parity", {}).get("final_tour_matches_golden", True) and
                                     all(v for d in out["other_configs"].values() for k, v in d.items()
                                         if k.startswith(("winner_", "every_"))))
