@@ -113,6 +113,61 @@ def test_large_odd_sizes_prefix_of_both_trajectories(eng, ctx, n, integer_coords
     inst.close()
 
 
+def _grid_instance(n):
+    return np.random.default_rng(n).integers(0, 700_000, size=(n, 2)).astype(np.float64)
+
+
+def test_full_alg_2opt_descent_beyond_the_lds_engines(eng, ctx):
+    """n = 20 011: no replica fits a CU's LDS, the whole first-improvement descent runs on the GRID engine (k_first, tour state
+    in HBM).  Final tour, cost and every counter against the oracle's committed vector (make_golden_grid.py)."""
+    g = golden("oracle_vectors_grid.json")["rand20011_first"]
+    xy = _grid_instance(20011)
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([g["start"]], dtype=np.int32))
+    assert obj[0] == g["greedy"]["obj"] and O.fnv1a(succ[0]) == g["greedy"]["hash"]
+    rc, s, o, st = inst.two_opt(succ[0], obj[0], mode=eng.FIRST)
+    inst.close()
+    f = g["final"]
+    assert rc == 0 and o == f["cost"] and O.fnv1a(s) == f["hash"]
+    assert (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == \
+        (f["stats"]["sweeps"], f["stats"]["evals"], f["stats"]["moves"], f["stats"]["reversed"])
+    assert st["exact_pairs"] == -1          # not the CLUSTER engine
+
+
+def test_more_nodes_than_a_uint16_id_holds(eng, ctx):
+    """n = 70 001 (the reference ships data/art/stefano_128k.tsp and pla85900): the LDS-resident engines index nodes with 16
+    bits and must not be picked; greedy, the first two best-improvement sweeps and the first 60 first-improvement moves on the
+    GRID engine equal the oracle's committed vectors.  The tabu stamp array of such an instance is refused (int index)."""
+    g = golden("oracle_vectors_grid.json")["rand70001"]
+    xy = _grid_instance(70001)
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    succ, obj, _ = inst.construct(eng.GREEDY, np.array([g["start"]], dtype=np.int32))
+    assert obj[0] == g["greedy"]["obj"] and O.fnv1a(succ[0]) == g["greedy"]["hash"]
+    tours = eng.Tours(inst, 1)
+    tours.upload(succ[0], obj[0])
+    rc, done = tours.run_engine(eng.BEST, engine=eng.ENGINE_AUTO, max_steps=2)
+    s, o, st = tours.download()
+    assert O.fnv1a(s[0]) == g["best_2_sweeps"]["hash"] and o[0] == g["best_2_sweeps"]["cost"] and st[0]["moves"] == 2
+    assert st[0]["evals"] == g["best_2_sweeps"]["evals"]
+    tours.reset()
+    moves = 0
+    for _ in range(2000):
+        tours.run(eng.FIRST, max_steps=1)
+        s, o, st = tours.download()
+        moves = st[0]["moves"]
+        if moves >= 60:
+            break
+    f = g["first_60_moves"]
+    assert moves == 60 and O.fnv1a(s[0]) == f["hash"] and o[0] == f["cost"] and st[0]["reversed"] == f["reversed"]
+    tours.close()
+    for engine in (eng.ENGINE_LDS, eng.ENGINE_CLUSTER):
+        with pytest.raises(eng.TspDeviceError):
+            inst.two_opt(succ[0], obj[0], mode=eng.FIRST, engine=engine)
+    with pytest.raises(eng.TspDeviceError):
+        eng.Tabu(inst)
+    inst.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_time_limit_stops_with_a_valid_tour_and_status_2(eng, ctx, mode):
     """TIME_LIMIT_EXCEEDED (include/heuristics.h:7): the descent stops between launch batches with a valid tour;

@@ -459,6 +459,24 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (*s_fail) failed = true;
         }
     }
+    // FIRST, evaluation count: adjacent pairs passed so far in this launch (adj_seen), the moves' corrections of the current
+    // sweep (adjD), the tour edges that lay behind the cursor when the launch took the sweep over (adjA0)
+    long long adj_seen = 0, adjD = 0, adjA0 = 0;
+    bool sweep_open = false;
+    auto edges_upto = [&](u64 K) -> long long {   // tour edges whose pair is <= K in scan order (block-wide; first workgroup only)
+        long long cnt = 0;
+        for (int p = tid; p < n; p += kClThreads) {
+            const int u = to_ext((int)order[p]), v = to_ext((int)order[p + 1 == n ? 0 : p + 1]);
+            cnt += make_key(min(u, v), max(u, v)) <= K ? 1 : 0;
+        }
+        return block_sum<long long>(cnt, s_ll);
+    };
+    if constexpr (!BEST) {
+        if (a.count_evals && c == 0 && !failed && (ci != 0 || cj != 0)) {
+            adjA0 = edges_upto(make_key(ci, cj));
+            sweep_open = true;
+        }
+    }
     bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
     for (int iter = 0; iter < a.max_iters && !done && !failed && !leave; ++iter) {
         int row_lo = 0, row_hi = n - 1;
@@ -468,7 +486,6 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         const int slot_cur = TABU ? (int)(sweeps % 3) : 0, slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
         int si = ci, sj = cj;    // FIRST: where the tiles scan starts (the probe moves it on when it finds nothing)
         bool probe_hit = false;
-        long long probe_adj = 0;
         if constexpr (!BEST) {
             // ---- probe: the next 512 pairs in scan order, one per thread (see two_opt_lds.hip) -----------------
             // Every workgroup of the cluster runs it on its own replica and gets the same answer: a step the probe
@@ -495,8 +512,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 }
                 w_lane += __popcll(__ballot(act));
                 w_ex += __popcll(__ballot(act && !adjp));
-                const unsigned long long hb = __ballot(hit), ab = __ballot(adjp);
-                if (lane == 0) { s_k[wave] = hb; s_ll[wave] = (long long)ab; }
+                const unsigned long long hb = __ballot(hit);
+                if (lane == 0) s_k[wave] = hb;
                 if (hb && lane == __builtin_ctzll(hb)) { s_d[wave] = delta; s_k[8 + wave] = make_key(i, j); s_ip[wave] = pip; }
                 int ei = ci, ej = cj + kClThreads;   // the last thread's pair: where the scan goes on after a probe without a hit
 #pragma unroll
@@ -505,20 +522,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 __syncthreads();
                 {   // every wave reads the eight wave results once (lane w: wave w) and reduces them in registers
                     const int lw = lane & (kClWaves - 1);
-                    const unsigned long long h = s_k[lw], am = (unsigned long long)s_ll[lw];
+                    const unsigned long long h = s_k[lw];
                     const double dw = s_d[lw];
                     const u64 kw = s_k[8 + lw];
                     const unsigned long long hm = __ballot(lane < kClWaves && h != 0ull);
                     probe_hit = hm != 0ull;
                     const int fw = probe_hit ? __builtin_ctzll(hm) : kClWaves;   // first wave with a hit
-                    const unsigned hlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)h, fw & (kClWaves - 1));
-                    const unsigned hhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(h >> 32), fw & (kClWaves - 1));
-                    const unsigned long long hw = ((unsigned long long)hhi << 32) | hlo;
-                    const int fl = hw ? __builtin_ctzll(hw) : 63;
-                    const unsigned long long keep = lw < fw ? ~0ull : (lw == fw ? ((2ull << fl) - 1ull) : 0ull);
-                    int ac = lane < kClWaves ? __popcll(am & keep) : 0;
-                    ac = wave_sum_to_lane63(ac);
-                    probe_adj = __builtin_amdgcn_readlane(ac, 63);
                     if (probe_hit) {
                         bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dw), fw), __builtin_amdgcn_readlane(__double2loint(dw), fw));
                         const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
@@ -973,23 +982,17 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         const int fi = found ? key_i(key) : -1, fj = found ? key_j(key) : -1;                       // the caller's ids of the same pair
 
         // ---- reference-equivalent evaluation count (FIRST; kept by the cluster's first workgroup) ----------------
-        long long adj = 0;
+        // evals = pairs between the old and the new cursor MINUS the adjacent ones among them (heuristics.c:471 skips those).
+        // The adjacent pairs are not counted step by step (that was a block-wide pass over the rows of the step by the
+        // first workgroup, for which the whole cluster then waited at the next exchange): over the steps of a sweep the
+        // counts telescope.  With A_t(K) = tour edges {u, v} whose pair key is <= K at step t, a step from cursor lo to hi
+        // skips A_t(hi) - A_t(lo) pairs, the next step starts at lo' = hi, and a move only changes four edges, so
+        //     sum over the steps = A_now(cursor) - A(cursor at the start) - sum over the moves of d_t,
+        //     d_t = [(i,j) <= hi] + [(a1,b1) <= hi] - [(i,a1) <= hi] - [(j,b1) <= hi],  hi = (i,j) the move's pair:
+        // O(1) per move (adjD), one pass over the tour per launch (A_now) instead of one per step.
         int ni = fi, nj = fj;
         if constexpr (!BEST) {
             if (!found) { ni = row_hi - 1; nj = n - 1; }
-            if (probe_hit) adj = probe_adj;   // counted by the probe's ballots
-            else if (a.count_evals && c == 0) {
-                const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
-                long long cnt = 0;
-                for (int r = ci + tid; r <= ni; r += kClThreads) {
-                    const int p = pos[to_int(r)];
-                    const int s = to_ext(order[p + 1 == n ? 0 : p + 1]), q = to_ext(order[p == 0 ? n - 1 : p - 1]);
-                    const u64 ks = make_key(r, s), kq = make_key(r, q);
-                    cnt += (s > r && ks > lo && ks <= hi) ? 1 : 0;
-                    cnt += (q > r && kq > lo && kq <= hi) ? 1 : 0;
-                }
-                adj = block_sum<long long>(cnt, s_ll);
-            }
         }
 
         CL_T(4);
@@ -997,6 +1000,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         int Lr = 0;
         if (found) {
             const int pa = pos[wi], pb = pos[wj];
+            if constexpr (!BEST) {
+                if (a.count_evals && c == 0) {   // d_t of this move, on the tour as it is before the move
+                    const int a1e = to_ext((int)order[pa + 1 == n ? 0 : pa + 1]), b1e = to_ext((int)order[pb + 1 == n ? 0 : pb + 1]);
+                    const u64 hi = make_key(fi, fj);
+                    auto le = [&](int u, int v) { return make_key(min(u, v), max(u, v)) <= hi ? 1 : 0; };
+                    adjD += 1 + le(a1e, b1e) - le(fi, a1e) - le(fj, b1e);
+                }
+            }
             int ga1 = 0, gb1 = 0;
             if constexpr (SORTED) {
                 ga1 = (int)order[pa + 1 == n ? 0 : pa + 1] >> 6;
@@ -1062,7 +1073,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         } else {
             const long long r_old = pair_rank(ci, cj, n), r_new = pair_rank(ni, nj, n);
             scanned += probe_hit ? kClThreads : pair_rank(row_hi - 1, n - 1, n) - r_old;
-            evals += r_new - r_old - adj;
+            evals += r_new - r_old;   // the adjacent pairs among them come off per sweep / per launch (adj_seen)
+            sweep_open = true;
             if (found) probe_on = r_new - r_old <= a.probe;
             if (found) {
                 obj += bd;                              // heuristics.c:486
@@ -1076,6 +1088,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 hit_rows = max(hit_rows, row_hi - ci);  // nothing within these rows: the next hit is at least that far
                 chunk = min(chunk * 2, a.rmax);
                 if (row_hi >= n - 1) {                  // sweep complete
+                    adj_seen += (long long)n - adjA0 - adjD;   // every tour edge has been passed
+                    adjD = 0; adjA0 = 0; sweep_open = false;
                     sweeps += 1;
                     if (obj >= seen) done = 1;          // heuristics.c:492
                     else { seen = obj; ci = 0; cj = 0; }
@@ -1115,6 +1129,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     // ---- write back (first workgroup of the cluster; a failed run leaves the tour in HBM untouched) ---------------------
     if (failed || c != 0) return;
     __syncthreads();
+    if constexpr (!BEST) {
+        if (a.count_evals) {
+            if (sweep_open) adj_seen += edges_upto(make_key(ci, cj)) - adjA0 - adjD;   // the sweep goes on in the next launch
+            evals -= adj_seen;
+        }
+    }
     int *pos_g = a.poss + (size_t)tour * n;
     for (int p0 = tid; p0 < n; p0 += LU * kClThreads) {
         int v[LU];
