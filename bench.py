@@ -506,7 +506,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tj):
             with open(tj) as f:
-                traffic = json.load(f).get("r02_cluster_descent_n10000_hbm_bytes_per_launch")
+                traffic = json.load(f).get("r03_cluster_descent_n10000_hbm_bytes_per_launch")
         exhaustive = {}
         if not args.no_variants:
             # the same sweep with every delta expression executed (tiled kernel k_recs + k_step, bounds off): the kernel
@@ -522,13 +522,13 @@ def main():
                           "exact_delta_per_s": ev_v / (ms_v * 1e-3), "bound": "valu", "ops_per_eval": OPS_EXACT,
                           "achieved": ev_v * OPS_EXACT / (ms_v * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
                           "unit": "T lane-op/s", "frac": ev_v * OPS_EXACT / (ms_v * 1e-3) / FP64_LANE_OPS_PEAK,
-                          "rocprof": "profiles/r02_kernel_stats_exhaustive.csv"}
+                          "rocprof": "profiles/r03_kernel_stats_exhaustive.csv"}
             tours_v.close()
             inst_v.close()
         out["roofline"] = {
             "kernel": "tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, BEST, float replica, sorted scan> -- one launch = "
                       "one whole descent (%d sweeps) on 256 workgroups; kernel_ms = HIP events on the engine's stream around one "
-                      "further descent after the timed region (rocprof mean: profiles/r02_kernel_stats.csv)" % sweeps,
+                      "further descent after the timed region (rocprof mean: profiles/r03_kernel_stats.csv)" % sweeps,
             "bound": "valu", "achieved": achieved / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
             "unit": "T lane-op/s (fp64 vector lane-instructions; peak = 78.6 TFLOP/s / 2; fp32 operations count 1/2)",
             "frac": achieved / FP64_LANE_OPS_PEAK, "traffic": traffic,

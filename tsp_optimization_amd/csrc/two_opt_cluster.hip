@@ -689,7 +689,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             if (tid == 0) { prof[6] += 1; prof[7] += cnt; }
 #endif
                         };
-                        constexpr int RU = 4;   // rows in flight per wave: their LDS reads are issued together
+                        constexpr int RU = 4;   // rows in flight per wave: their LDS reads are issued together (2 and 8 measure the same: 15.9 ms per descent)
                         for (int k0 = wave * RU; k0 < nit; k0 += kClWaves * RU) {
                             int ridx[RU], cidx[RU], ee[RU];
                             bool valid[RU], need[RU];
