@@ -368,17 +368,34 @@ def main():
     dist_info = {}
     if dist is not None:
         import torch
-        idt = torch.zeros(E.COMM_ID_BYTES, dtype=torch.uint8, device=device)
-        if rank == 0:
-            try:
-                idt.copy_(torch.frombuffer(bytearray(E.comm_unique_id()), dtype=torch.uint8))
-            except Exception as e:   # noqa: BLE001 -- reported in the line
-                dist_info["c_abi_comm_error"] = repr(e)
-        dist.broadcast(idt, src=0)
-        raw = idt.cpu().numpy().tobytes()
-        if any(raw):
-            comm = E.Comm(ctx, world, rank, raw)
-            dist_info["c_abi_comm"] = "tsp_dev_comm_init_rank over RCCL %d" % comm.rccl_version()
+
+        def all_agree(flag):   # min over the ranks of a 0 / 1 flag: every rank takes the same branch
+            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        # tsp_dev_comm_init_rank is collective: only enter it when EVERY rank can load RCCL through the C ABI and rank 0 has an id
+        if all_agree(E.comm_available()):
+            idt = torch.zeros(E.COMM_ID_BYTES, dtype=torch.uint8, device=device)
+            if rank == 0:
+                try:
+                    idt.copy_(torch.frombuffer(bytearray(E.comm_unique_id()), dtype=torch.uint8))
+                except Exception as e:   # noqa: BLE001 -- reported in the line; travels to the other ranks as an all-zero id
+                    dist_info["c_abi_comm_error"] = repr(e)
+            dist.broadcast(idt, src=0)
+            raw = idt.cpu().numpy().tobytes()
+            if any(raw):
+                try:
+                    comm = E.Comm(ctx, world, rank, raw)
+                except Exception as e:   # noqa: BLE001
+                    dist_info["c_abi_comm_error"] = repr(e)
+                if not all_agree(comm is not None):   # some rank failed after the rendezvous: nobody uses the C communicator
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+            if comm is not None:
+                dist_info["c_abi_comm"] = "tsp_dev_comm_init_rank over RCCL %d" % comm.rccl_version()
+        else:
+            dist_info["c_abi_comm_error"] = "librccl could not be opened through the C ABI on some rank"
         one = torch.ones(1, dtype=torch.int64, device=device)
         dist.all_reduce(one)
         dist_info["rccl_ranks_seen"] = int(one.item())

@@ -244,6 +244,9 @@ int tsp_dev_tours_best(tsp_dev_tours *t, int true_cost, int64_t *packed);
  * group return TSP_DEV_E_COMM with the text in tsp_dev_comm_last_error(). ------------------------------------------------ */
 #define TSP_COMM_ID_BYTES 128
 const char *tsp_dev_comm_last_error(void);
+/* 1 if librccl could be opened (dlopen) and holds every symbol this group needs, else 0.  Forms no communicator: a rank can
+ * ask before it enters the collective tsp_dev_comm_init_rank, in which a rank that cannot load RCCL would leave the others waiting. */
+int tsp_dev_comm_available(void);
 /* One process per GPU: rank 0 obtains the id (ncclGetUniqueId) and hands its TSP_COMM_ID_BYTES to every rank by a side
  * channel of the caller's choice; then every rank calls init_rank with its own context (collective: returns when all have). */
 int tsp_dev_comm_unique_id(char *id);

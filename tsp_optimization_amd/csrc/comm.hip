@@ -129,6 +129,8 @@ extern "C" {
 
 const char *tsp_dev_comm_last_error(void) { return g_comm_error; }
 
+int tsp_dev_comm_available(void) { return rccl() ? 1 : 0; }
+
 int tsp_dev_comm_unique_id(char *id) {
     if (!id) return TSP_DEV_E_ARG;
     const Rccl *R = rccl();

@@ -114,7 +114,7 @@ EXPORTED = [
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
     "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
-    "tsp_dev_comm_last_error", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
+    "tsp_dev_comm_last_error", "tsp_dev_comm_available", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
     "tsp_dev_comm_info", "tsp_dev_multistart_pack", "tsp_dev_multistart_allreduce", "tsp_dev_multistart_bcast_tour",
     "tsp_dev_multistart_allreduce_group", "tsp_dev_multistart_bcast_tour_group",
 ]
@@ -426,6 +426,11 @@ def multistart_pack(cost, start_id):
     if lib().tsp_dev_multistart_pack(float(cost), int(start_id), C.byref(p)) != OK:
         raise ValueError("cost %r / start %r cannot be packed for the all-reduce(min)" % (cost, start_id))
     return p.value
+
+
+def comm_available():
+    """True if librccl can be opened by the C ABI (no communicator is formed)."""
+    return bool(lib().tsp_dev_comm_available())
 
 
 def comm_unique_id():
