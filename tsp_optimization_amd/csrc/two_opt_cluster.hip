@@ -85,6 +85,7 @@ struct ClusterArgs {
     int tabu_list_cap, iter, tenure;
     unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
+    int use_b0;             // BEST, sorted scan: start every sweep from the bound the previous exchange yields (TSP_CLUSTER_B0)
     int fs_rows;            // FIRST on the sorted replica: a step takes the box-pruned scan when the running mean of the rows between hits is at least this
     int fs_exit;            // FIRST, plain replica: the launch ends when that mean reaches this (the host goes on with the rank-order variant); 0 = never
     int fs_leave;           // FIRST, rank-order replica: the launch ends when the mean falls below this (back to the plain variant); 0 = never
@@ -217,6 +218,8 @@ struct ClCand {
     double d;
     u64 key;
     unsigned ipair;
+    double b0 = 0.0;   // out (best improvement, sorted scan): the best delta among the OTHER candidates that the winner's move does
+                       // not touch -- still a valid pair with that delta on the new tour, hence a bound for the next sweep
 };
 
 // ---- the exchange: one candidate per workgroup and step -------------------------------------------------------
@@ -233,7 +236,7 @@ struct ClCand {
 // reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
 template <bool BEST, bool SORTED, bool SMALLD>
 __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err, unsigned spin_limit,
-                                            unsigned long long spin_ticks) {
+                                            unsigned long long spin_ticks, const idx_t *pos = nullptr, int n = 0) {
     constexpr int NG = 1 + (SORTED ? 1 : 0) + (SMALLD ? 1 : 2);
     constexpr int GD = SORTED ? 2 : 1;   // first delta granule
     const int lane = threadIdx.x & 63;
@@ -317,6 +320,36 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
     unsigned wip = 0;
     if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
     cd.d = wd; cd.key = wk; cd.ipair = wip;
+    if constexpr (BEST && SORTED) {
+        // The bound the next sweep starts from.  The winner's move reverses the tour positions pa+1 .. pb and changes the successor
+        // of exactly those nodes and of a = the winner's first node.  A candidate (u, v) of another workgroup with neither node among
+        // them keeps succ u, succ v, its adjacency and therefore its delta: the next sweep's minimum is at most that.  Every
+        // workgroup holds all C candidates here and computes the same value.
+        double b0 = 0.0;
+        if (pos != nullptr && wk != kNoKey && wd < 0.0) {
+            const int wi = (int)(wip >> 16), wj = (int)(wip & 0xffffu);
+            const int pa = (int)pos[wi], pb = (int)pos[wj];
+            int L = pb - pa; if (L < 0) L += n;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int k = q * 64 + lane;
+                if (k < C && (unsigned)g[q][0] != 0xffffffffu) {
+                    double d;
+                    if constexpr (SMALLD) d = (double)(int)(unsigned)g[q][GD];
+                    else d = __longlong_as_double((long long)((g[q][GD] & 0xffffffffull) | (g[q][GD + 1] << 32)));
+                    const unsigned ip2 = (unsigned)g[q][1];
+                    const int ui = (int)(ip2 >> 16), uj = (int)(ip2 & 0xffffu);
+                    int du = (int)pos[ui] - pa - 1, dv = (int)pos[uj] - pa - 1;
+                    if (du < 0) du += n;
+                    if (dv < 0) dv += n;
+                    const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
+                    if (untouched && d < b0) b0 = d;
+                }
+            }
+            b0 = from_ordered_bits(wave_min_u64(ordered_bits(b0)));
+        }
+        cd.b0 = b0;
+    }
     return true;
 }
 
@@ -358,6 +391,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     int *s_fail = reinterpret_cast<int *>(scratch + 468);
     static_assert(kClWaves <= 8, "scratch carve-up: eight wave winners");
     unsigned *s_ip = reinterpret_cast<unsigned *>(scratch + 480);      // 8: the waves' winners (internal pairs)
+    double *s_b0 = reinterpret_cast<double *>(scratch + 256 + 15 * 8);  // the next sweep's bound (s_ll[15]: block sums use 0 .. 7, the final counters come after the loop)
     int *s_nitems = reinterpret_cast<int *>(scratch + 476);   // the workgroup's own winner (before the exchange)
     double *s_chunk = reinterpret_cast<double *>(scratch + 512);       // 64 doubles (fcost cost recompute)
     float4 *s_rowsf = reinterpret_cast<float4 *>(scratch + 512);       // tiles scan, float replica: x, y, edge length of the tile's rows (shares the chunk: that is used at the end of a run only)
@@ -477,10 +511,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             sweep_open = true;
         }
     }
+    double b0 = 0.0;      // BEST, sorted scan: bound the sweep starts from (<= 0; see cl_exchange)
     bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
     for (int iter = 0; iter < a.max_iters && !done && !failed && !leave; ++iter) {
         int row_lo = 0, row_hi = n - 1;
-        double bd = 0.0;
+        double bd = (SORTED && BEST) ? b0 : 0.0;   // every lane starts from the bound; a lane without a pair keeps key == kNoKey
         u64 key = kNoKey;
         unsigned ipair = 0;
         const int slot_cur = TABU ? (int)(sweeps % 3) : 0, slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
@@ -570,8 +605,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         const int r = e >> 16, cg = e & 0xffff;
                         const double4 rb = gbox[r], cb = gbox[cg];
                         const double gx = fmax(0.0, fmax(rb.x - cb.y, cb.x - rb.y)), gy = fmax(0.0, fmax(rb.z - cb.w, cb.z - rb.w));
-                        const double T = gmax[r] + gmax[cg] + prune2;   // bound 0: nothing is known about this sweep yet
-                        surv = gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+                        const double T = gmax[r] + gmax[cg] + prune2 + (BEST ? b0 : 0.0);   // b0: what is known about this sweep before it starts
+                        surv = T > 0.0 && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
                         if (a.dbg & 4) surv = true;
                     }
                     const unsigned long long bal = __ballot(surv);
@@ -615,8 +650,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         if (row_side) {   // wave-uniform
                             const double4 cb = gbox[cgp];
                             const double gx = fmax(0.0, fmax(cb.x - rec.x, rec.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rec.y, rec.y - cb.w));
-                            const double T = rec.ds + gmax[cgp] + prune2;
-                            const bool reach = (a.dbg & 2) ? v < n : gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
+                            const double T = rec.ds + gmax[cgp] + prune2 + (BEST ? b0 : 0.0);
+                            const bool reach = (a.dbg & 2) ? v < n : (T > 0.0 && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T));
                             const unsigned long long m = __ballot(reach);
                             if (m) {
                                 int base = 0;
@@ -906,8 +941,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
-            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks);
-            if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks,
+                                                              (SORTED && BEST && a.use_b0) ? pos : nullptr, n);
+            if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; *s_b0 = cd.b0; }
         }
         if constexpr (TABU) {
             if (wave != 0) {
@@ -966,6 +1002,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             __syncthreads();
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
+            if constexpr (SORTED && BEST) b0 = *s_b0;
         }
         if constexpr (TABU) {
             if (c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
@@ -1462,6 +1499,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu_side = tabu->d_tabu_pairs;
     }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
+    a.use_b0 = TSP_SW(inst, CLUSTER_B0, 1);
     a.fs_rows = fs_rows;
     a.fs_exit = fs_avail ? fs_rows : 0;
     a.fs_leave = fs_avail ? std::max(1, fs_rows / 4) : 0;
