@@ -35,7 +35,7 @@ using idx_t = unsigned short;
 __host__ __device__ inline size_t lds_bytes_needed(int n, bool edge_cache = false) {
     // rows | coord | order | pos | (edge lengths by position) | reduction scratch
     return sizeof(NodeRec) * kLdsRows + sizeof(double2) * (size_t)n + 2 * sizeof(idx_t) * (size_t)n +
-           (edge_cache ? sizeof(float) * (size_t)n + 16 : 0) + 1024;
+           (edge_cache ? sizeof(float) * (size_t)n + 16 : 0) + 1024 + 512;   // + the rows' float records (fp32 first tier)
 }
 
 // Node record from the LDS arrays.  CACHE: d(v, succ v) is dsp[pos v] -- the tour's edge lengths by position, kept
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
                                                              int rmax, int count_evals, int max_iters, double margin, double prune,
-                                                             int probe, int probe2) {
+                                                             int probe, int probe2, double org_x, double org_y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NodeRec *s_rows = reinterpret_cast<NodeRec *>(smem);
     double2 *coord = reinterpret_cast<double2 *>(smem + sizeof(NodeRec) * kLdsRows);
@@ -81,6 +81,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     double *s_chunk = reinterpret_cast<double *>(scratch + 384);  // 64 doubles (fcost cost recompute)
     int4 *s_win = reinterpret_cast<int4 *>(scratch + 384);        // 8 (FIRST, the probe's vote): shares the chunk, which only BEST uses
     int *s_flag = reinterpret_cast<int *>(scratch + 384 + 384);   // FIRST: second probe round
+    float4 *s_rowsf = reinterpret_cast<float4 *>(scratch + 1024);  // x, y (relative to the instance corner), edge length of the block's rows as floats
+    // Integer coordinates of bounded span are exact as floats relative to the instance corner: the new-edge bound runs in fp32
+    // first (its rounding paid for in slack: s may come out 2^-22 low, T -- below 2^23 -- is taken 2 units high), four rows per
+    // trip, before the row's full record and the fp64 tiers are looked at -- as in the CLUSTER engine's tiles scan
+    constexpr bool F32T0 = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
+    constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
 
     const int tour = blockIdx.x;
     const int tid = threadIdx.x;
@@ -297,7 +303,11 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         for (int rb = row_lo; rb < row_hi && !probe_hit; rb += kLdsRows) {
             const int nr = min(kLdsRows, row_hi - rb);
             __syncthreads();
-            if (tid < nr) s_rows[tid] = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, rb + tid);
+            if (tid < nr) {
+                const NodeRec rr = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, rb + tid);
+                s_rows[tid] = rr;
+                if constexpr (F32T0) s_rowsf[tid] = make_float4((float)(rr.x - org_x), (float)(rr.y - org_y), (float)rr.ds, 0.f);
+            }
             __syncthreads();
             // Columns four at a time: a column record is a chain of dependent LDS reads (pos -> order / edge length ->
             // successor's coordinates); the four chains advance level by level, so a thread waits for LDS three
@@ -338,6 +348,64 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const unsigned long long q1 = clock64();
 #endif
+                if constexpr (F32T0) {
+                    NodeRec rjv[U];
+                    float cxf[U], cyf[U], cdf[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        rjv[k].x = cxy[k].x; rjv[k].y = cxy[k].y; rjv[k].xs = cs[k].x; rjv[k].ys = cs[k].y;
+                        if constexpr (CACHE) rjv[k].ds = dsv[k];
+                        else rjv[k].ds = dist_xy<WT, INT>(cxy[k].x, cxy[k].y, cs[k].x, cs[k].y);
+                        rjv[k].succ = sc[k]; rjv[k].id = jj[k];
+                        cxf[k] = (float)(cxy[k].x - org_x); cyf[k] = (float)(cxy[k].y - org_y); cdf[k] = (float)rjv[k].ds;
+                    }
+                    constexpr int RQ = 4;   // rows per trip: four LDS reads in flight, one vote
+                    for (int r0 = 0; r0 < nr; r0 += RQ) {
+                        float4 rf[RQ];
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) rf[u] = s_rowsf[min(r0 + u, nr - 1)];
+                        const float bf = (float)((MODE == TSP_2OPT_FIRST ? 0.0 : bd) + 2.0 * prune + 2.0);
+                        bool need[RQ][U];
+                        bool any = false;
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) {
+#pragma unroll
+                            for (int k = 0; k < U; ++k) {
+                                const float dx = rf[u].x - cxf[k], dy = rf[u].y - cyf[k], T = rf[u].z + cdf[k] + bf;
+                                need[u][k] = act[k] && r0 + u < nr && fmaf(dx, dx, dy * dy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
+                                any = any || need[u][k];
+                            }
+                        }
+                        if (!__any(any)) continue;
+#pragma unroll
+                        for (int u = 0; u < RQ; ++u) {
+#pragma unroll
+                            for (int k = 0; k < U; ++k) {
+                                if (!__any(need[u][k])) continue;
+                                const int i = rb + r0 + u, j = jj[k];
+                                const NodeRec ri = s_rows[r0 + u];
+                                const NodeRec &rj = rjv[k];
+                                const u64 kq = make_key(i, j);
+                                bool ok = need[u][k] && j > i && j != ri.succ && rj.succ != i;   // heuristics.c:471 / tabusearch.c:134
+                                if constexpr (MODE == TSP_2OPT_FIRST) ok = ok && (i > si || j > sj) && kq < key;
+                                const double bound = (MODE == TSP_2OPT_FIRST) ? 0.0 : bd;
+                                ok = ok && new_edge_can_improve<WT>(ri.x, ri.y, rj.x, rj.y, bound + ri.ds + rj.ds + 2.0 * prune);
+                                if (ok) {
+                                    const double lower = pair_delta_approx<WT>(ri, rj) - margin;
+                                    ok = MODE == TSP_2OPT_FIRST ? lower < bound : lower <= bound;
+                                }
+                                if (ok) {
+                                    const double delta = pair_delta<WT, INT>(ri, rj);
+                                    if constexpr (MODE == TSP_2OPT_FIRST) {
+                                        if (delta < 0) { bd = delta; key = kq; }
+                                    } else {
+                                        if (better(delta, kq, bd, key)) { bd = delta; key = kq; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     if (!act[k]) continue;
@@ -374,6 +442,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                             }
                         }
                     }
+                }
                 }
 #ifdef TSP_STAMPS
                 const unsigned long long q2 = clock64();
@@ -550,7 +619,8 @@ hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
         granted = bytes;
     }
     hipLaunchKernelGGL(k, dim3(t->B), dim3(kLdsThreads), bytes, s, t->inst->d_coord, t->d_order, t->d_state, t->n,
-                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, TSP_SW(t->inst, LDS_PROBE, 65536), TSP_SW(t->inst, LDS_PROBE2, 1));
+                       rmin, rmax, t->count_evals, max_iters, t->inst->filter_margin, t->inst->prune_margin, TSP_SW(t->inst, LDS_PROBE, 65536), TSP_SW(t->inst, LDS_PROBE2, 1),
+                       t->inst->org_x, t->inst->org_y);
     return hipGetLastError();
 }
 
