@@ -57,7 +57,7 @@ __device__ __forceinline__ NodeRec lds_node(const double2 *coord, const idx_t *o
     return r;
 }
 
-template <int WT, bool INT, int MODE, bool CACHE>
+template <int WT, bool INT, int MODE, bool CACHE, bool F32>
 __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__restrict__ coord_g,
                                                              int *__restrict__ orders_g,
                                                              TourState *__restrict__ states, int n, int rmin,
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     // Integer coordinates of bounded span are exact as floats relative to the instance corner: the new-edge bound runs in fp32
     // first (its rounding paid for in slack: s may come out 2^-22 low, T -- below 2^23 -- is taken 2 units high), four rows per
     // trip, before the row's full record and the fp64 tiers are looked at -- as in the CLUSTER engine's tiles scan
-    constexpr bool F32T0 = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
+    // (a variant of its own, chosen by the host from 2 500 nodes on (128 random tours, on / off: n = 2 000 48.9 / 46.6 ms, 3 000 99.5 / 101.5, 5 000 200 / 210): rand5000 x 128 random individuals 216 -> 205 ms, but att532 x 256
+    //  GRASP starts 2.95 -> 3.7 ms -- short rows, dense hits: the trip of four rows costs more than it prunes; and with both forms
+    //  in one kernel behind a run-time switch both were 5-8 % slower)
+    constexpr bool F32T0 = F32 && (WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD);
     constexpr bool ATT10 = WT == WT_ATT || WT == WT_ATT_ICOORD;
 
     const int tour = blockIdx.x;
@@ -107,9 +110,26 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
               scanned = st->pairs_scanned, steps = st->steps;
     bool probe_on = true;                       // FIRST: the last hit lay within `probe` pairs of the cursor
     bool after_hit = true;                      // FIRST: the step before found a move (TSP_LDS_PROBE2=1: the second round only then)
-    long long adj_acc = 0;                      // this thread's share of the adjacent pairs the reference skipped (heuristics.c:471)
+    // Evaluation count: pairs between the old and the new cursor minus the adjacent ones among them (heuristics.c:471).  The
+    // adjacent pairs telescope over the steps of a sweep (two_opt_cluster.hip has the derivation): with A(K) = tour edges whose
+    // pair key is <= K, a sweep's total is A_now(cursor) - A(cursor at the start) - sum over its moves of
+    // d = 1 + [(a1,b1) <= hi] - [(i,a1) <= hi] - [(j,b1) <= hi], hi = (i,j) the move's pair: O(1) per move, one pass over the
+    // tour per launch, instead of a pass over the step's rows (and ballots in the probes) in every step.
+    long long adj_seen = 0, adjD = 0, adjA0 = 0;
+    bool sweep_open = false;
+    auto edges_upto = [&](u64 K) -> long long {
+        long long cnt = 0;
+        for (int p = tid; p < n; p += kLdsThreads) {
+            const int u = (int)order[p], v = (int)order[p + 1 == n ? 0 : p + 1];
+            cnt += make_key(min(u, v), max(u, v)) <= K ? 1 : 0;
+        }
+        return block_sum<long long>(cnt, s_ll);
+    };
     long long r_cur = pair_rank(ci, cj, n);     // rank of the cursor in scan order
     __syncthreads();
+    if constexpr (MODE == TSP_2OPT_FIRST) {
+        if (count_evals && (ci != 0 || cj != 0)) { adjA0 = edges_upto(make_key(ci, cj)); sweep_open = true; }
+    }
     if constexpr (CACHE) {
         for (int p = tid; p < n; p += kLdsThreads) {
             const double2 c = coord[order[p]], cs = coord[order[p + 1 == n ? 0 : p + 1]];
@@ -130,7 +150,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         // scan cursor: where the rows x columns scan below starts (the probe moves it on when it finds nothing)
         int si = ci, sj = cj;
         bool probe_hit = false;
-        long long probe_adj = 0;
         int4 win = make_int4(0, 0, 0, 0);   // probe hit: positions of the pair's nodes and their successors
         if constexpr (MODE == TSP_2OPT_FIRST) {
             // ---- probe: the next 512 pairs in scan order, one per thread --------------------------------------
@@ -170,15 +189,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                         hit = delta < 0;
                     }
                 }
-                const unsigned long long hb = __ballot(hit), ab = __ballot(adjp);
+                const unsigned long long hb = __ballot(hit);
 #ifdef TSP_STAMPS
                 const unsigned long long pq2 = clock64();
 #endif
                 const int wv = tid >> 6, ln = tid & 63;
-                if (ln == 0) {
-                    s_k[wv] = hb;
-                    s_ll[wv] = (long long)ab;
-                }
+                if (ln == 0) s_k[wv] = hb;
                 if (tid == 0) *s_flag = 1 << 20;   // second round: smallest m with a hit so far
                 if (hb && ln == __builtin_ctzll(hb)) {
                     s_d[wv] = delta; s_k[8 + wv] = make_key(i, j);
@@ -197,22 +213,13 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 {   // every wave reads the eight wave results once (lane w: wave w) and reduces them in registers
                     constexpr int NWV = kLdsThreads / 64;
                     const int lw = ln & (NWV - 1);
-                    const unsigned long long h = s_k[lw], am = (unsigned long long)s_ll[lw];
+                    const unsigned long long h = s_k[lw];
                     const double dw = s_d[lw];
                     const u64 kw = s_k[8 + lw];
                     const int4 ww = s_win[lw];
                     const unsigned long long hm = __ballot(ln < NWV && h != 0ull);
                     probe_hit = hm != 0ull;
                     const int fw = probe_hit ? __builtin_ctzll(hm) : NWV;   // first wave with a hit
-                    const unsigned hlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)h, fw & (NWV - 1));
-                    const unsigned hhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(h >> 32), fw & (NWV - 1));
-                    const unsigned long long hw = ((unsigned long long)hhi << 32) | hlo;
-                    const int fl = hw ? __builtin_ctzll(hw) : 63;
-                    // adjacent pairs up to the hit (all of them when there is none)
-                    const unsigned long long keep = lw < fw ? ~0ull : (lw == fw ? ((2ull << fl) - 1ull) : 0ull);
-                    int ac = ln < NWV ? __popcll(am & keep) : 0;
-                    ac = wave_sum_to_lane63(ac);
-                    probe_adj = __builtin_amdgcn_readlane(ac, 63);
                     if (probe_hit) {
                         bd = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dw), fw), __builtin_amdgcn_readlane(__double2loint(dw), fw));
                         const unsigned klo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kw, fw);
@@ -237,7 +244,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                     int4 *s_win2 = s_win + 8;
                     u64 *s_key2 = reinterpret_cast<u64 *>(s_win + 16);
                     const int ln = tid & 63, wv = tid >> 6;
-                    unsigned adjm = 0;
                     bool hit = false;
                     int hm = 0, hi_ = 0, hj_ = 0, ha1 = 0, hb1 = 0;
                     double hd = 0.0;
@@ -248,8 +254,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                         const NodeRec ri = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, i);
                         const NodeRec rj = lds_node<WT, INT, CACHE>(coord, order, pos, dsp, n, j);
                         const bool adjp = j == ri.succ || rj.succ == i;   // heuristics.c:471
-                        if (adjp) adjm |= 1u << m;
-                        else {
+                        if (!adjp) {
                             const double delta = pair_delta<WT, INT>(ri, rj);
                             if (delta < 0) { hit = true; hm = m; hi_ = i; hj_ = j; ha1 = ri.succ; hb1 = rj.succ; hd = delta; }
                         }
@@ -280,10 +285,6 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                             key = ((u64)khi << 32) | klo;
                             win.x = __builtin_amdgcn_readlane(ww.x, fw); win.y = __builtin_amdgcn_readlane(ww.y, fw);
                             win.z = __builtin_amdgcn_readlane(ww.z, fw); win.w = __builtin_amdgcn_readlane(ww.w, fw);
-                            // this thread's adjacent pairs before the winner (the first 512 pairs' are in probe_adj already)
-#pragma unroll
-                            for (int m = 0; m < R2; ++m)
-                                if ((adjm >> m & 1u) && (long long)kLdsThreads * (m + 1) + tid < twin) adj_acc += 1;
                         } else {   // nothing in these 2 560 pairs: the scan goes on behind them
                             int ei2 = ci, ej2 = cj + kLdsThreads * (R2 + 1);
                             while (ej2 >= n) { ej2 = ej2 - n + ei2 + 2; ei2 += 1; }
@@ -463,24 +464,10 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         const bool found = key != kNoKey && (MODE == TSP_2OPT_FIRST || bd < 0);
         const int wi = found ? key_i(key) : -1, wj = found ? key_j(key) : -1;
 
-        // ---- reference-equivalent evaluation count (FIRST) -----------------------------------------
-        long long adj = 0;
+        // ---- reference-equivalent evaluation count (FIRST): see adj_seen above ------------------------------
         int ni = wi, nj = wj;
         if constexpr (MODE == TSP_2OPT_FIRST) {
             if (!found) { ni = row_hi - 1; nj = n - 1; }
-            if (probe_hit) adj = probe_adj;   // counted by the probe's ballots
-            else if (count_evals) {
-                const u64 lo = make_key(ci, cj), hi = make_key(ni, nj);
-                long long c = 0;
-                for (int r = ci + tid; r <= ni; r += kLdsThreads) {
-                    const int p = pos[r];
-                    const int s = order[p + 1 == n ? 0 : p + 1], q = order[p == 0 ? n - 1 : p - 1];
-                    const u64 ks = make_key(r, s), kq = make_key(r, q);
-                    c += (s > r && ks > lo && ks <= hi) ? 1 : 0;
-                    c += (q > r && kq > lo && kq <= hi) ? 1 : 0;
-                }
-                adj_acc += c;   // summed over the workgroup once, at the end of the launch
-            }
         }
 
         LDS_T(2);
@@ -490,6 +477,14 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             // a probe hit carries the positions and successors along: nobody reads the tour between its vote and the swaps,
             // so the barrier that otherwise separates those reads from the swaps is not needed
             const int pa = probe_hit ? win.x : (int)pos[wi], pb = probe_hit ? win.y : (int)pos[wj];
+            if constexpr (MODE == TSP_2OPT_FIRST) {
+                if (count_evals) {   // d of this move, on the tour as it is before the move
+                    const int a1 = probe_hit ? win.z : (int)order[pa + 1 == n ? 0 : pa + 1], b1 = probe_hit ? win.w : (int)order[pb + 1 == n ? 0 : pb + 1];
+                    const u64 hi = make_key(wi, wj);
+                    auto le = [&](int u, int v) { return make_key(min(u, v), max(u, v)) <= hi ? 1 : 0; };
+                    adjD += 1 + le(a1, b1) - le(wi, a1) - le(wj, b1);
+                }
+            }
             float new_edge = 0.f;
             if constexpr (CACHE) {
                 // the two new edges (a, b) and (succ a, succ b) will leave positions pa and pb, which the reversal of the
@@ -562,7 +557,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         } else {
             const long long r_new = pair_rank(ni, nj, n);
             scanned += probe_hit ? r_new - r_cur : (found ? pair_rank(row_hi - 1, n - 1, n) : r_new) - r_cur;
-            evals += r_new - r_cur - adj;
+            evals += r_new - r_cur;   // the adjacent pairs among them come off per sweep / per launch (adj_seen)
+            sweep_open = true;
             after_hit = found;
             if (found) probe_on = r_new - r_cur <= probe;   // (also switching it off after a step without a hit: measured, slower)
             r_cur = r_new;
@@ -573,6 +569,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
             } else {
                 chunk = min(chunk * 2, rmax);
                 if (row_hi >= n - 1) {                  // sweep complete
+                    adj_seen += (long long)n - adjA0 - adjD;   // every tour edge has been passed
+                    adjD = 0; adjA0 = 0; sweep_open = false;
                     sweeps += 1;
                     if (obj >= seen) done = 1;          // heuristics.c:492
                     else { seen = obj; ci = 0; cj = 0; r_cur = 0; }
@@ -586,7 +584,12 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
 #endif
     // ---- write back ---------------------------------------------------------------------------------------
     __syncthreads();
-    if constexpr (MODE == TSP_2OPT_FIRST) evals -= block_sum<long long>(adj_acc, s_ll);
+    if constexpr (MODE == TSP_2OPT_FIRST) {
+        if (count_evals) {
+            if (sweep_open) adj_seen += edges_upto(make_key(ci, cj)) - adjA0 - adjD;   // the sweep goes on in the next launch
+            evals -= adj_seen;
+        }
+    }
     for (int v = tid; v < n; v += kLdsThreads) order_g[v] = (int)order[v];
     if (tid == 0) {
         st->ci = ci; st->cj = cj; st->chunk_rows = chunk; st->done = done; st->obj = obj; st->seen_cost = seen;
@@ -606,11 +609,11 @@ double wall_s() {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-template <int WT, bool INT, int MODE, bool CACHE>
+template <int WT, bool INT, int MODE, bool CACHE, bool F32>
 hipError_t launch_lds_k(tsp_dev_tours *t, int rmin, int rmax, int max_iters) {
     hipStream_t s = t->inst->ctx->stream;
     const size_t bytes = lds_bytes_needed(t->n, CACHE);
-    auto k = k_lds_two_opt<WT, INT, MODE, CACHE>;
+    auto k = k_lds_two_opt<WT, INT, MODE, CACHE, F32>;
     static size_t granted_dev[64] = {0};   // per kernel variant and device
     size_t &granted = granted_dev[t->inst->ctx->device & 63];
     if (bytes > granted) {
@@ -629,12 +632,18 @@ hipError_t launch_lds(tsp_dev_tours *t, int mode, int rmin, int rmax, int max_it
     // integer-coordinate variants: integer edge lengths < 2^21, exact as floats
     constexpr bool CAN_CACHE = WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD;
     if constexpr (CAN_CACHE) {
-        if (lds_bytes_needed(t->n, true) <= (size_t)t->inst->ctx->lds_bytes && TSP_SW(t->inst, LDS_EDGE_CACHE, 1))
-            return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, true>(t, rmin, rmax, max_iters)
-                                          : launch_lds_k<WT, INT, TSP_2OPT_BEST, true>(t, rmin, rmax, max_iters);
+        const bool f32 = t->n >= TSP_SW(t->inst, LDS_F32_MIN_N, 2500);   // the fp32 first tier of the rows x columns scan
+        if (lds_bytes_needed(t->n, true) <= (size_t)t->inst->ctx->lds_bytes && TSP_SW(t->inst, LDS_EDGE_CACHE, 1)) {
+            if (f32) return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, true, true>(t, rmin, rmax, max_iters)
+                                                   : launch_lds_k<WT, INT, TSP_2OPT_BEST, true, true>(t, rmin, rmax, max_iters);
+            return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, true, false>(t, rmin, rmax, max_iters)
+                                          : launch_lds_k<WT, INT, TSP_2OPT_BEST, true, false>(t, rmin, rmax, max_iters);
+        }
+        if (f32) return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, false, true>(t, rmin, rmax, max_iters)
+                                               : launch_lds_k<WT, INT, TSP_2OPT_BEST, false, true>(t, rmin, rmax, max_iters);
     }
-    return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, false>(t, rmin, rmax, max_iters)
-                                  : launch_lds_k<WT, INT, TSP_2OPT_BEST, false>(t, rmin, rmax, max_iters);
+    return mode == TSP_2OPT_FIRST ? launch_lds_k<WT, INT, TSP_2OPT_FIRST, false, false>(t, rmin, rmax, max_iters)
+                                  : launch_lds_k<WT, INT, TSP_2OPT_BEST, false, false>(t, rmin, rmax, max_iters);
 }
 }  // namespace
 
