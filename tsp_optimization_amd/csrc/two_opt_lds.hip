@@ -503,16 +503,28 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
                 // one loop for both reversals (tour positions pa+1 .. pb; the edge lengths between them, positions
                 // pa+1 .. pb-1, which keep their values and change places): all four reads of a trip are in flight together
                 const int inner = (L - 1) >> 1;
-                for (int t = tid; t < half; t += kLdsThreads) {
-                    int p = pa + 1 + t; if (p >= n) p -= n;
-                    int q = pb - t; if (q < 0) q += n;
-                    int q1 = q - 1; if (q1 < 0) q1 += n;
-                    const idx_t u = order[p], w = order[q];
-                    const bool in = t < inner;
-                    const float du = dsp[p], dw = dsp[q1];
-                    order[p] = w; order[q] = u;
-                    pos[w] = (idx_t)p; pos[u] = (idx_t)q;
-                    if (in) { dsp[p] = dw; dsp[q1] = du; }
+                // two trips of a thread at a time: the eight reads of both are in flight together (a random tour's reversal is
+                // ~800 swaps, i.e. two trips per thread, and a trip is a chain of LDS latencies)
+                for (int t0 = tid; t0 < half; t0 += 2 * kLdsThreads) {
+                    const int t1 = t0 + kLdsThreads;
+                    const bool two = t1 < half;
+                    int p0 = pa + 1 + t0; if (p0 >= n) p0 -= n;
+                    int q0 = pb - t0; if (q0 < 0) q0 += n;
+                    int r0 = q0 - 1; if (r0 < 0) r0 += n;
+                    int p1 = pa + 1 + t1; if (p1 >= n) p1 -= n;
+                    int q1 = pb - t1; if (q1 < 0) q1 += n;
+                    int r1 = q1 - 1; if (r1 < 0) r1 += n;
+                    if (!two) { p1 = p0; q1 = q0; r1 = r0; }
+                    const idx_t u0 = order[p0], w0 = order[q0], u1 = order[p1], w1 = order[q1];
+                    const float du0 = dsp[p0], dw0 = dsp[r0], du1 = dsp[p1], dw1 = dsp[r1];
+                    order[p0] = w0; order[q0] = u0;
+                    pos[w0] = (idx_t)p0; pos[u0] = (idx_t)q0;
+                    if (t0 < inner) { dsp[p0] = dw0; dsp[r0] = du0; }
+                    if (two) {
+                        order[p1] = w1; order[q1] = u1;
+                        pos[w1] = (idx_t)p1; pos[u1] = (idx_t)q1;
+                        if (t1 < inner) { dsp[p1] = dw1; dsp[r1] = du1; }
+                    }
                 }
                 if (tid < 2) dsp[tid == 0 ? pa : pb] = new_edge;
             } else {
