@@ -1045,12 +1045,33 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     adjD += 1 + le(a1e, b1e) - le(fi, a1e) - le(fj, b1e);
                 }
             }
-            int ga1 = 0, gb1 = 0;
-            if constexpr (SORTED) {
-                ga1 = (int)order[pa + 1 == n ? 0 : pa + 1] >> 6;
-                gb1 = (int)order[pb + 1 == n ? 0 : pb + 1] >> 6;
+            if constexpr (FS) { if (!do_sorted) gmax_dirty = true; }
+            if constexpr (SORTED) if (!gmax_dirty) {
+                // The move changes the incident edges of four nodes only -- a: (a, a1) becomes (a, b); a1: (a, a1) becomes (a1, b1);
+                // b: (b, b1) becomes (a, b); b1: (b, b1) becomes (a1, b1) -- every other node keeps its two tour neighbours whatever
+                // the orientation.  So the bounds of their four groups are rebuilt from the OLD tour with those four edges patched,
+                // beside the reads of pa / pb and before the swaps: no barrier between the swaps and a rebuild.
+                const int a1 = (int)order[pa + 1 == n ? 0 : pa + 1], b1 = (int)order[pb + 1 == n ? 0 : pb + 1];
+                if (a.dbg & 1) {
+                    gmax_dirty = true;   // diagnostics: every bound rebuilt after the swaps (below)
+                } else if (wave < 4) {
+                    const int g = wave == 0 ? (wi >> 6) : (wave == 1 ? (wj >> 6) : (wave == 2 ? (a1 >> 6) : (b1 >> 6)));
+                    const int v = g * 64 + lane;
+                    double m = 0.0;
+                    if (v < n) {
+                        const int p = (int)pos[v];
+                        int su = (int)order[p + 1 == n ? 0 : p + 1], pr = (int)order[p == 0 ? n - 1 : p - 1];
+                        if (v == wi) su = wj;            // a -> b
+                        else if (v == wj) su = wi;       // b's old successor b1 gives way to a
+                        if (v == a1) pr = b1;            // a1's old predecessor a gives way to b1
+                        else if (v == b1) pr = a1;       // b1's old predecessor b gives way to a1
+                        m = fmax(cl_dist<WT, INT, CT>(coord, v, su), cl_dist<WT, INT, CT>(coord, v, pr));
+                    }
+                    m = cl_wave_max_nonneg(m);
+                    if (lane == 0) gmax[g] = m;
+                }
             }
-            __syncthreads();   // everyone has read pa / pb (and finished the adjacency reads)
+            __syncthreads();   // everyone has read pa / pb (and finished the bound rebuild)
             Lr = pb - pa; if (Lr < 0) Lr += n;
             const int half = Lr >> 1;
             for (int t = tid; t < half; t += kClThreads) {
@@ -1060,15 +1081,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 order[p] = w; order[q] = u;
                 pos[w] = (idx_t)p; pos[u] = (idx_t)q;
             }
-            if constexpr (FS) { if (!do_sorted) gmax_dirty = true; }
-            if constexpr (SORTED) if (!gmax_dirty) {
-                __syncthreads();
-                // the move changes the incident edges of a, succ a, b, succ b only: their groups' bounds are rebuilt
-                if (a.dbg & 1) {
+            if constexpr (SORTED && BEST) {
+                if (gmax_dirty) {   // TSP_CLUSTER_DEBUG & 1: every bound from the new tour
+                    __syncthreads();
                     group_bounds(wave, kClWaves, ng);
-                } else if (wave < 4) {
-                    const int g = wave == 0 ? (wi >> 6) : (wave == 1 ? (wj >> 6) : (wave == 2 ? ga1 : gb1));
-                    group_bounds(g, 1, g + 1);
+                    gmax_dirty = false;
                 }
             }
         }
