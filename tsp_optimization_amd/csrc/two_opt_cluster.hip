@@ -85,6 +85,7 @@ struct ClusterArgs {
     int tabu_list_cap, iter, tenure;
     unsigned long long *tabu_side;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
+    int defer_moves;        // carry the swaps of a move out during the next step's exchange (TSP_CLUSTER_DEFER)
     int use_b0;             // BEST, sorted scan: start every sweep from the bound the previous exchange yields (TSP_CLUSTER_B0)
     int fs_rows;            // FIRST on the sorted replica: a step takes the box-pruned scan when the running mean of the rows between hits is at least this
     int fs_exit;            // FIRST, plain replica: the launch ends when that mean reaches this (the host goes on with the rank-order variant); 0 = never
@@ -191,6 +192,34 @@ __device__ __forceinline__ NodeRec cl_node(const CT *coord, const idx_t *order, 
     return r;
 }
 
+// A pending reversal of the tour positions pa+1 .. pb (L of them, cyclic; L == 0: none): the move has been decided, the swaps
+// have not been carried out yet.  Position p holds afterwards what its mirror inside the range holds now.
+struct ClView {
+    int pa, pb, L;
+};
+__device__ __forceinline__ int cl_mirror(const ClView &m, int p, int n) {
+    int d = p - m.pa - 1;
+    if (d < 0) d += n;
+    if (d >= m.L) return p;
+    int q = m.pb - d;
+    if (q < 0) q += n;
+    return q;
+}
+// cl_node on the tour as it will be once the pending reversal has been carried out
+template <int WT, bool INT, typename CT>
+__device__ __forceinline__ NodeRec cl_node_v(const CT *coord, const idx_t *order, const idx_t *pos, int n, int v, const ClView &m) {
+    if (m.L == 0) return cl_node<WT, INT, CT>(coord, order, pos, n, v);   // wave-uniform
+    const int p = cl_mirror(m, (int)pos[v], n);
+    const int q = p + 1 == n ? 0 : p + 1;
+    const int s = (int)order[cl_mirror(m, q, n)];
+    const CT c = coord[v], cs = coord[s];
+    NodeRec r;
+    r.x = (double)c.x; r.y = (double)c.y; r.xs = (double)cs.x; r.ys = (double)cs.y;
+    r.ds = dist_xy<WT, INT>(r.x, r.y, r.xs, r.ys);
+    r.succ = s; r.id = v;
+    return r;
+}
+
 template <int WT, bool INT, typename CT>
 __device__ __forceinline__ double cl_dist(const CT *coord, int u, int v) {
     const CT a = coord[u], b = coord[v];
@@ -218,9 +247,36 @@ struct ClCand {
     double d;
     u64 key;
     unsigned ipair;
-    double b0 = 0.0;   // out (best improvement, sorted scan): the best delta among the OTHER candidates that the winner's move does
-                       // not touch -- still a valid pair with that delta on the new tour, hence a bound for the next sweep
+    // out (best improvement, sorted scan): this lane's share of the cluster's candidates (internal pair, delta; 0 = none), from
+    // which the caller derives the bound the next sweep starts from (cl_next_bound)
+    unsigned c_ip[4] = {0u, 0u, 0u, 0u};
+    double c_d[4] = {0.0, 0.0, 0.0, 0.0};
 };
+
+// The bound the next sweep starts from.  The winner's move reverses the tour positions pa+1 .. pb and changes the successor of
+// exactly those nodes and of a = the winner's first node.  A candidate (u, v) of another workgroup with neither node among them
+// keeps succ u, succ v, its adjacency and therefore its delta: the next sweep's minimum is at most that.  Every workgroup holds
+// all C candidates after an exchange and computes the same value.  One wave; pos[] as it stands when the winner's positions are read.
+__device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *pos, int n) {
+    double b0 = 0.0;
+    if (cd.key != kNoKey && cd.d < 0.0) {
+        const int wi = (int)(cd.ipair >> 16), wj = (int)(cd.ipair & 0xffffu);
+        const int pa = (int)pos[wi], pb = (int)pos[wj];
+        int L = pb - pa; if (L < 0) L += n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (cd.c_d[q] < 0.0) {
+                const int ui = (int)(cd.c_ip[q] >> 16), uj = (int)(cd.c_ip[q] & 0xffffu);
+                int du = (int)pos[ui] - pa - 1, dv = (int)pos[uj] - pa - 1;
+                if (du < 0) du += n;
+                if (dv < 0) dv += n;
+                const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
+                if (untouched && cd.c_d[q] < b0) b0 = cd.c_d[q];
+            }
+        }
+    }
+    return from_ordered_bits(wave_min_u64(ordered_bits(b0)));
+}
 
 // ---- the exchange: one candidate per workgroup and step -------------------------------------------------------
 // Producer: lane 0 of the workgroup's first wave, NG 8-byte sc1 stores {epoch, payload}.  Consumer: the first wave of
@@ -236,7 +292,7 @@ struct ClCand {
 // reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
 template <bool BEST, bool SORTED, bool SMALLD>
 __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err, unsigned spin_limit,
-                                            unsigned long long spin_ticks, const idx_t *pos = nullptr, int n = 0) {
+                                            unsigned long long spin_ticks) {
     constexpr int NG = 1 + (SORTED ? 1 : 0) + (SMALLD ? 1 : 2);
     constexpr int GD = SORTED ? 2 : 1;   // first delta granule
     const int lane = threadIdx.x & 63;
@@ -321,34 +377,17 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
     if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
     cd.d = wd; cd.key = wk; cd.ipair = wip;
     if constexpr (BEST && SORTED) {
-        // The bound the next sweep starts from.  The winner's move reverses the tour positions pa+1 .. pb and changes the successor
-        // of exactly those nodes and of a = the winner's first node.  A candidate (u, v) of another workgroup with neither node among
-        // them keeps succ u, succ v, its adjacency and therefore its delta: the next sweep's minimum is at most that.  Every
-        // workgroup holds all C candidates here and computes the same value.
-        double b0 = 0.0;
-        if (pos != nullptr && wk != kNoKey && wd < 0.0) {
-            const int wi = (int)(wip >> 16), wj = (int)(wip & 0xffffu);
-            const int pa = (int)pos[wi], pb = (int)pos[wj];
-            int L = pb - pa; if (L < 0) L += n;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int k = q * 64 + lane;
-                if (k < C && (unsigned)g[q][0] != 0xffffffffu) {
-                    double d;
-                    if constexpr (SMALLD) d = (double)(int)(unsigned)g[q][GD];
-                    else d = __longlong_as_double((long long)((g[q][GD] & 0xffffffffull) | (g[q][GD + 1] << 32)));
-                    const unsigned ip2 = (unsigned)g[q][1];
-                    const int ui = (int)(ip2 >> 16), uj = (int)(ip2 & 0xffffu);
-                    int du = (int)pos[ui] - pa - 1, dv = (int)pos[uj] - pa - 1;
-                    if (du < 0) du += n;
-                    if (dv < 0) dv += n;
-                    const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
-                    if (untouched && d < b0) b0 = d;
-                }
+        for (int q = 0; q < Q; ++q) {
+            const int k = q * 64 + lane;
+            cd.c_ip[q] = 0u; cd.c_d[q] = 0.0;
+            if (k < C && (unsigned)g[q][0] != 0xffffffffu) {
+                double d;
+                if constexpr (SMALLD) d = (double)(int)(unsigned)g[q][GD];
+                else d = __longlong_as_double((long long)((g[q][GD] & 0xffffffffull) | (g[q][GD + 1] << 32)));
+                cd.c_ip[q] = (unsigned)g[q][1]; cd.c_d[q] = d;
             }
-            b0 = from_ordered_bits(wave_min_u64(ordered_bits(b0)));
         }
-        cd.b0 = b0;
     }
     return true;
 }
@@ -511,7 +550,30 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             sweep_open = true;
         }
     }
-    double b0 = 0.0;      // BEST, sorted scan: bound the sweep starts from (<= 0; see cl_exchange)
+    double b0 = 0.0;      // BEST, sorted scan: bound the sweep starts from (<= 0; see cl_next_bound)
+    // Deferred moves.  The swaps of a move that an EXCHANGE step decided are not carried out at once: the next step scans the tour
+    // through the closed form of the pending reversal (ClView), and the swaps are done by waves 1 .. 7 while wave 0 runs that
+    // step's exchange -- time they would spend waiting for it.  (Not with a tabu list: those waves work on the list then.  Not for
+    // C == 1: no exchange to hide behind.  A move decided by the probe is carried out at once, after any pending one.)
+    ClView view{0, 0, 0};
+    const bool defer_on = !TABU && C > 1 && a.defer_moves;
+    auto swaps = [&](const ClView &m, int t0, int stride) {   // the reversal itself, by the threads t0, t0 + stride, ...
+        const int half = m.L >> 1;
+        for (int t = t0; t < half; t += stride) {
+            int p = m.pa + 1 + t; if (p >= n) p -= n;
+            int q = m.pb - t; if (q < 0) q += n;
+            const idx_t u = order[p], w = order[q];
+            order[p] = w; order[q] = u;
+            pos[w] = (idx_t)p; pos[u] = (idx_t)q;
+        }
+    };
+    auto flush_view = [&]() {   // workgroup-wide: carry the pending reversal out now
+        if (view.L != 0) {      // the same in every thread
+            swaps(view, tid, kClThreads);
+            view.L = 0;
+            __syncthreads();
+        }
+    };
     bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
     for (int iter = 0; iter < a.max_iters && !done && !failed && !leave; ++iter) {
         int row_lo = 0, row_hi = n - 1;
@@ -536,8 +598,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 double delta = 0.0;
                 unsigned pip = 0;
                 if (act) {
-                    const NodeRec ri = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(i));
-                    const NodeRec rj = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(j));
+                    const NodeRec ri = cl_node_v<WT, INT, CT>(coord, order, pos, n, to_int(i), view);
+                    const NodeRec rj = cl_node_v<WT, INT, CT>(coord, order, pos, n, to_int(j), view);
                     adjp = rj.id == ri.succ || rj.succ == ri.id;   // heuristics.c:471
                     if (!adjp) {
                         delta = pair_delta<WT, INT>(ri, rj);
@@ -586,6 +648,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         if constexpr (SORTED) if (do_sorted) {
             if constexpr (FS) {
                 if (gmax_dirty) {   // wave-uniform, the same in every workgroup
+                    flush_view();
                     group_bounds(wave, kClWaves, ng);
                     gmax_dirty = false;
                     __syncthreads();
@@ -645,7 +708,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         const int v = g * 64 + (x & 63);
                         NodeRec rec;
                         rec.x = rec.y = rec.xs = rec.ys = 1e30; rec.ds = 0.0; rec.succ = -1; rec.id = -1;   // padding: far from everything
-                        if (v < n) rec = cl_node<WT, INT, CT>(coord, order, pos, n, v);
+                        if (v < n) rec = cl_node_v<WT, INT, CT>(coord, order, pos, n, v, view);
                         stage[x] = SR::pack(rec);
                         if (row_side) {   // wave-uniform
                             const double4 cb = gbox[cgp];
@@ -816,13 +879,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 __syncthreads();
                 constexpr bool F32T0 = std::is_same<CT, float2>::value && has_root_filter<WT>();
                 if (tid < nr) {
-                    const NodeRec rr = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(rb + tid));
+                    const NodeRec rr = cl_node_v<WT, INT, CT>(coord, order, pos, n, to_int(rb + tid), view);
                     s_rows[tid] = rr;
                     if constexpr (F32T0) s_rowsf[tid] = make_float4((float)rr.x, (float)rr.y, (float)rr.ds, 0.f);
                 }
                 NodeRec rj;
                 const bool act = j < n && j > rb;
-                if (act) rj = cl_node<WT, INT, CT>(coord, order, pos, n, to_int(j));
+                if (act) rj = cl_node_v<WT, INT, CT>(coord, order, pos, n, to_int(j), view);
                 __syncthreads();
                 CL_T(9);
 #ifdef TSP_STAMPS
@@ -920,6 +983,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         // ---- the workgroup's candidate, the cluster's winner -----------------------------------------------------
         // wave arg-min (the winner's internal pair rides along: a pair is evaluated by exactly one lane), the eight wave
         // winners through LDS to the first wave, which reduces them, runs the exchange and hands the result back
+        ClCand xcd{0.0, kNoKey, 0u};   // wave 0: the exchange's result with this lane's share of the candidates
         if (!probe_hit) {
             const u64 mykey = key;
             wave_argmin<BEST>(bd, key);
@@ -941,9 +1005,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
-            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks,
-                                                              (SORTED && BEST && a.use_b0) ? pos : nullptr, n);
-            if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; *s_b0 = cd.b0; }
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks);
+            if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
+            xcd = cd;
+        } else if (!probe_hit && view.L != 0) {
+            swaps(view, tid - 64, kClThreads - 64);   // the pending reversal, while wave 0 exchanges
         }
         if constexpr (TABU) {
             if (wave != 0) {
@@ -1002,7 +1068,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             __syncthreads();
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
-            if constexpr (SORTED && BEST) b0 = *s_b0;
+            view.L = 0;   // carried out by waves 1 .. 7 before this barrier (an exchange step with a pending reversal)
         }
         if constexpr (TABU) {
             if (c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
@@ -1036,6 +1102,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         // ---- move: reverse positions pa+1 .. pb (cyclic), src/utility.c:708-717 ------------------------------------
         int Lr = 0;
         if (found) {
+            flush_view();   // a probe step: the reversal an exchange step left pending comes first (no-op after an exchange step)
             const int pa = pos[wi], pb = pos[wj];
             if constexpr (!BEST) {
                 if (a.count_evals && c == 0) {   // d_t of this move, on the tour as it is before the move
@@ -1043,6 +1110,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     const u64 hi = make_key(fi, fj);
                     auto le = [&](int u, int v) { return make_key(min(u, v), max(u, v)) <= hi ? 1 : 0; };
                     adjD += 1 + le(a1e, b1e) - le(fi, a1e) - le(fj, b1e);
+                }
+            }
+            if constexpr (SORTED && BEST) {
+                if (a.use_b0 && wave == 0 && C > 1) {   // the bound the next sweep starts from (the exchanging wave holds the candidates)
+                    const double nb0 = cl_next_bound(xcd, pos, n);
+                    if (lane == 0) *s_b0 = nb0;
                 }
             }
             if constexpr (FS) { if (!do_sorted) gmax_dirty = true; }
@@ -1071,25 +1144,25 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     if (lane == 0) gmax[g] = m;
                 }
             }
-            __syncthreads();   // everyone has read pa / pb (and finished the bound rebuild)
             Lr = pb - pa; if (Lr < 0) Lr += n;
-            const int half = Lr >> 1;
-            for (int t = tid; t < half; t += kClThreads) {
-                int p = pa + 1 + t; if (p >= n) p -= n;
-                int q = pb - t; if (q < 0) q += n;
-                const idx_t u = order[p], w = order[q];
-                order[p] = w; order[q] = u;
-                pos[w] = (idx_t)p; pos[u] = (idx_t)q;
-            }
-            if constexpr (SORTED && BEST) {
-                if (gmax_dirty) {   // TSP_CLUSTER_DEBUG & 1: every bound from the new tour
-                    __syncthreads();
-                    group_bounds(wave, kClWaves, ng);
-                    gmax_dirty = false;
+            const bool dbg_rebuild = SORTED && BEST && gmax_dirty;
+            if (defer_on && !probe_hit && !dbg_rebuild) {
+                view.pa = pa; view.pb = pb; view.L = Lr;   // carried out during the next step's exchange
+            } else {
+                __syncthreads();   // everyone has read pa / pb (and finished the bound rebuild)
+                ClView now{pa, pb, Lr};
+                swaps(now, tid, kClThreads);
+                if constexpr (SORTED && BEST) {
+                    if (gmax_dirty) {   // TSP_CLUSTER_DEBUG & 1: every bound from the new tour
+                        __syncthreads();
+                        group_bounds(wave, kClWaves, ng);
+                        gmax_dirty = false;
+                    }
                 }
             }
         }
         __syncthreads();
+        if constexpr (SORTED && BEST) b0 = (a.use_b0 && found && C > 1) ? *s_b0 : 0.0;
 
         CL_T(5);
         // ---- control block ------------------------------------------------------------------------------------------
@@ -1158,6 +1231,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][7] += steps - st->steps; }
     if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
 #endif
+    if (!failed) flush_view();   // a reversal the last exchange step left pending
     if (!failed) {
         // executed-work counters: every workgroup adds its share to a slot of its own (read and summed by tsp_dev_tours_download).
         // As 8 x 256 atomics on four words of one cache line they were the largest single item of a short launch (~70 us of 86).
@@ -1517,6 +1591,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
     a.use_b0 = TSP_SW(inst, CLUSTER_B0, 1);
+    a.defer_moves = TSP_SW(inst, CLUSTER_DEFER, 1);
     a.fs_rows = fs_rows;
     a.fs_exit = fs_avail ? fs_rows : 0;
     a.fs_leave = fs_avail ? std::max(1, fs_rows / 4) : 0;
