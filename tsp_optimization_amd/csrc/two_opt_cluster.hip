@@ -1127,8 +1127,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 const int a1 = (int)order[pa + 1 == n ? 0 : pa + 1], b1 = (int)order[pb + 1 == n ? 0 : pb + 1];
                 if (a.dbg & 1) {
                     gmax_dirty = true;   // diagnostics: every bound rebuilt after the swaps (below)
-                } else if (wave < 4) {
-                    const int g = wave == 0 ? (wi >> 6) : (wave == 1 ? (wj >> 6) : (wave == 2 ? (a1 >> 6) : (b1 >> 6)));
+                } else if (wave >= 1 && wave <= 4) {   // (wave 0 computes the next sweep's bound meanwhile)
+                    const int g = wave == 1 ? (wi >> 6) : (wave == 2 ? (wj >> 6) : (wave == 3 ? (a1 >> 6) : (b1 >> 6)));
                     const int v = g * 64 + lane;
                     double m = 0.0;
                     if (v < n) {
