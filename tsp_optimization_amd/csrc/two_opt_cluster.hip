@@ -876,7 +876,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 const int jmin = (!BEST && nr == 1 && rb == si) ? max(rb, sj) : rb;
                 if (b * kClThreads + kClThreads - 1 <= jmin) continue;
                 CL_T(8);
-                __syncthreads();
+                // the row records of the tile before are still being read by slower waves -- not for a step's first tile: the last
+                // readers of s_rows finished before the arg-min barrier of the step before
+                if (t != c) __syncthreads();
                 constexpr bool F32T0 = std::is_same<CT, float2>::value && has_root_filter<WT>();
                 if (tid < nr) {
                     const NodeRec rr = cl_node_v<WT, INT, CT>(coord, order, pos, n, to_int(rb + tid), view);
@@ -1101,6 +1103,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         CL_T(4);
         // ---- move: reverse positions pa+1 .. pb (cyclic), src/utility.c:708-717 ------------------------------------
         int Lr = 0;
+        bool deferred_now = false;
         if (found) {
             flush_view();   // a probe step: the reversal an exchange step left pending comes first (no-op after an exchange step)
             const int pa = pos[wi], pb = pos[wj];
@@ -1148,6 +1151,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             const bool dbg_rebuild = SORTED && BEST && gmax_dirty;
             if (defer_on && !probe_hit && !dbg_rebuild) {
                 view.pa = pa; view.pb = pb; view.L = Lr;   // carried out during the next step's exchange
+                deferred_now = true;
             } else {
                 __syncthreads();   // everyone has read pa / pb (and finished the bound rebuild)
                 ClView now{pa, pb, Lr};
@@ -1161,7 +1165,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 }
             }
         }
-        __syncthreads();
+        // End of the step.  Nothing was written since the exchange's barrier when the move was deferred on the plain replica (no
+        // swaps, no group bounds, no bound for the next sweep): the next step's first shared writes are the probe's / the arg-min's
+        // per-wave slots and, behind a barrier of their own, the row records -- none of which this step still reads.
+        if (!(deferred_now && !SORTED)) __syncthreads();
         if constexpr (SORTED && BEST) b0 = (a.use_b0 && found && C > 1) ? *s_b0 : 0.0;
 
         CL_T(5);
