@@ -674,6 +674,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     }
                     const unsigned long long bal = __ballot(surv);
                     if (lane == 0) s_wcount[wave] = __popcll(bal);
+                    if (tid == 0) *s_nitems = 0;   // for the first chunk of survivors below (its readers are behind two barriers)
                     __syncthreads();
                     int before = 0, total = 0;
 #pragma unroll
@@ -696,9 +697,11 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 //      a row that happen to need them.
                 for (int e0 = 0; e0 < kept; e0 += P) {
                     const int ne = min(P, kept - e0);
-                    if (tid == 0) *s_nitems = 0;
                     if (wave == 0) w_st += ne * 128;
-                    __syncthreads();
+                    if (e0 > 0) {   // (the first chunk: zeroed beside the box tests, whose second barrier stands between)
+                        if (tid == 0) *s_nitems = 0;
+                        __syncthreads();
+                    }
                     for (int x = tid; x < ne * 128; x += kClThreads) {   // whole waves: ne * 128 is a multiple of 64
                         const int pe = x >> 7;
                         const int e = s_list[e0 + pe];
@@ -850,7 +853,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         if (qtail > qhead) dense(qtail - qhead);
                     }
                     CL_T(10);
-                    __syncthreads();   // the stage (and, after the last chunk, the list) is rewritten next
+                    // the stage (and, after a round's last chunk, the list) is rewritten next -- not after the last chunk of the last
+                    // round: what follows is the arg-min, whose per-wave slots nobody is reading
+                    if (!(e0 + P >= kept && m0 >= a.ntests)) __syncthreads();
                 }
             }
         }
