@@ -1,0 +1,93 @@
+// Micro-benchmark: the latency of one all-to-all round of tagged 8-byte granules between G resident workgroups, as the
+// CLUSTER engine's exchange does it (one store per workgroup, one wave of every workgroup sweeps all G until every tag
+// carries the round).  Varies: G, which workgroups take part (every `stride`-th of a 256-workgroup grid: stride 8 = one
+// XCD when workgroups are dealt to the XCDs in turn; the XCC id of every participant is printed), and the scope of the
+// stores / loads (agent = sc1, workgroup = sc0).
+// build: hipcc --offload-arch=gfx950 -O3 -o xchg xchg.hip ; run: ./xchg
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef unsigned long long u64;
+
+template <int SCOPE, int NG>
+__global__ __launch_bounds__(64) void k_xchg(u64 *area, int stride, int rounds, int *xcc, int *err, int work, int copies, int cstride, int nsleep, int perm) {
+    if (blockIdx.x % stride) return;
+    const int G = gridDim.x / stride, c0 = blockIdx.x / stride, lane = threadIdx.x;
+    const int c = perm ? (c0 % 8) * (G / 8) + c0 / 8 : c0;   // perm: the granules of one XCD's workgroups side by side
+    if (lane == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc[c0] = (int)(id & 0xf);
+    }
+    double acc = lane;
+    unsigned myx;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(myx));
+    const int mycopy = copies == 8 ? (int)(myx & 7) : c % copies;   // eight copies: one per XCD
+    for (int r = 1; r <= rounds; ++r) {
+        // stand-in for the scan between two exchanges (dependent fp64 chain)
+        for (int w = 0; w < work; ++w) acc = fma(acc, 1.0000001, 0.5);
+        u64 *par = area + (size_t)(r & 1) * 256 * NG;   // copy k of a parity: + k * cstride granules
+        const u64 tag = (u64)r << 32;
+        if (lane < copies) {
+#pragma unroll
+            for (int w = 0; w < NG; ++w) __hip_atomic_store(par + (size_t)lane * cstride + w * 256 + c, tag | (unsigned)c | (acc < 0 ? 1u : 0u), __ATOMIC_RELAXED, SCOPE);
+        }
+        const u64 *mine = par + (size_t)mycopy * cstride;
+        bool have[4];
+        for (int q = 0; q < 4; ++q) have[q] = q * 64 + lane >= G;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q * 64 < G && !have[q]) {
+                    u64 g[NG];
+#pragma unroll
+                    for (int w = 0; w < NG; ++w) g[w] = __hip_atomic_load(mine + w * 256 + q * 64 + lane, __ATOMIC_RELAXED, SCOPE);
+                    have[q] = true;
+#pragma unroll
+                    for (int w = 0; w < NG; ++w) have[q] = have[q] && (g[w] >> 32) == (u64)r;
+                    ok = ok && have[q];
+                }
+            }
+            if (__all(ok)) break;
+            if (++spins > (1u << 17)) { if (lane == 0) *err = 1; return; }
+            if (nsleep == 1) __builtin_amdgcn_s_sleep(1); else if (nsleep == 4) __builtin_amdgcn_s_sleep(4); else if (nsleep == 16) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    if (acc == 12345.678) area[600] = 1;
+}
+
+template <int SCOPE, int NG = 1>
+void run(const char *name, int stride, int work, int copies = 1, int cstride = 512, int nsleep = 1, int perm = 0) {
+    u64 *area; int *xcc, *err;
+    const size_t bytes = 8 * (size_t)(64 * cstride + 4096); hipMalloc(&area, bytes); hipMemset(area, 0, bytes);
+    hipMalloc(&xcc, 4 * 256); hipMalloc(&err, 4); hipMemset(err, 0, 4);
+    const int rounds = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipMemset(area, 0, bytes);
+        hipEventRecord(e0);
+        k_xchg<SCOPE, NG><<<256, 64>>>(area, stride, rounds, xcc, err, work, copies, cstride, nsleep, perm);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    int G = 256 / stride, h_err = 0;
+    std::vector<int> hx(G);
+    hipMemcpy(hx.data(), xcc, 4 * G, hipMemcpyDeviceToHost);
+    hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost);
+    unsigned seen = 0;
+    for (int i = 0; i < G; ++i) seen |= 1u << hx[i];
+    printf("%-10s NG %d G %3d (stride %d) work %4d copies %2d (every %d granules) sleep %2d perm %d: %.3f us per round, XCC mask 0x%02x%s\n", name, NG, G, stride, work, copies, cstride, nsleep, perm, 1e3 * best / rounds, seen, h_err ? "  GAVE UP" : "");
+    hipFree(area); hipFree(xcc); hipFree(err);
+}
+
+int main() {
+    for (int rep = 0; rep < 2; ++rep)
+        for (int perm : {0, 1})
+            for (int copies : {1, 4, 8}) run<__HIP_MEMORY_SCOPE_AGENT, 3>("agent", 1, 0, copies, 4128, 1, perm);
+    return 0;
+}

@@ -46,6 +46,7 @@ constexpr int kClListCap = kClThreads;   // surviving group pairs a workgroup ho
 
 constexpr int kClQueue = 128;      // per-wave ring of pairs waiting for tiers 1 and 2 (entries; a power of two >= 128)
 constexpr int kClSlotGranules = 4; // granules per workgroup and parity in the exchange area
+constexpr int kClCopies = 8;       // copies of the exchange area (TSP_CLUSTER_COPIES): every producer writes all, a workgroup sweeps the one of its XCD
 constexpr unsigned kClSpinLimit = 1u << 20;   // sweeps of the exchange area before a workgroup gives up (~ seconds): the backstop
 constexpr int kClSpinMs = 50;                 // ... and the time a workgroup waits for its peers' tags (TSP_CLUSTER_SPIN_MS): a step
                                               // takes microseconds, so tens of milliseconds without a tag mean a peer is not resident
@@ -74,7 +75,8 @@ struct ClusterArgs {
     const int *iid;         // sorted: node -> internal id
     const double4 *gbox;    // sorted: group boxes {min x, max x, min y, max y}
     const int *pairtab;     // sorted: C x ntests group pairs (r << 16 | c, -1 = none), nearest first, dealt in turn
-    unsigned long long *slots;   // B x 2 x C x kClSlotGranules
+    unsigned long long *slots;   // B x 2 x kClCopies x C x kClSlotGranules
+    int copies;                  // copies in use (1 ... kClCopies)
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
     // BEST, sorted scan, with a tabu list (two_opt_tabu_list.hpp has the method): stamps, the compact list of the non-zero
@@ -292,13 +294,15 @@ __device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *p
 // reads it.  Returns false when the sweep gave up (a peer is not resident): *err is raised.
 template <bool BEST, bool SORTED, bool SMALLD>
 __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned ep, ClCand &cd, int *err, unsigned spin_limit,
-                                            unsigned long long spin_ticks) {
+                                            unsigned long long spin_ticks, int copies, int mycopy) {
     constexpr int NG = 1 + (SORTED ? 1 : 0) + (SMALLD ? 1 : 2);
     constexpr int GD = SORTED ? 2 : 1;   // first delta granule
     const int lane = threadIdx.x & 63;
     const u64 tag = (u64)ep << 32;
-    gu64 *par = area + (size_t)(ep & 1u) * C * kClSlotGranules;
-    if (lane == 0) {
+    // Copies: a round among 256 workgroups costs 2.6 us when all of them sweep the same 16 - 48 lines and 2.2 us when the
+    // sweepers of each XCD have lines of their own (tools/ubench/xchg.hip); the stores of the copies are one instruction
+    gu64 *par = area + (size_t)(ep & 1u) * kClCopies * C * kClSlotGranules + (size_t)(lane < copies ? lane : 0) * C * kClSlotGranules;
+    if (lane < copies) {
         const u64 db = (u64)__double_as_longlong(cd.d);
         const unsigned kp = cd.key == kNoKey ? 0xffffffffu : (((unsigned)key_i(cd.key) & 0xffffu) << 16) | ((unsigned)key_j(cd.key) & 0xffffu);
         __hip_atomic_store(par + c, tag | kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -310,6 +314,7 @@ __device__ __forceinline__ bool cl_exchange(gu64 *area, int C, int c, unsigned e
             __hip_atomic_store(par + (GD + 1) * C + c, tag | (db >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    par = area + (size_t)(ep & 1u) * kClCopies * C * kClSlotGranules + (size_t)mycopy * C * kClSlotGranules;
     constexpr int Q = 4;   // C <= 256: at most four candidates per lane
     u64 g[Q][NG];
     bool have[Q];          // candidate q of this lane is complete: later passes leave it alone (fewer requests on the hot lines)
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     TourState *st = a.states + tour;
     if (st->done) return;
     int *order_g = a.orders + (size_t)tour * n;
-    gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * C * kClSlotGranules;
+    gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * kClCopies * C * kClSlotGranules;
 
     // the replica: eight loads per thread in flight at a time (a launch loads 120 KB per workgroup at n = 10 000; one load per
     // thread and trip was ~40 dependent memory latencies -- most of the fixed cost of a short resident run)
@@ -515,6 +520,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 #ifdef TSP_STAMPS
     unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
 #endif
+    int mycopy = 0;   // the copy of the exchange area this workgroup sweeps: its XCD's (any assignment is correct: every copy holds everything)
+    if (a.copies > 1) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        mycopy = (int)(xcc & 0xfu) % a.copies;
+    }
     unsigned xep = a.epoch0;   // exchange epochs (a step decided by the probe has none); slots hold smaller ones from earlier launches
     bool probe_on = true;    // FIRST: the last hit lay close to the cursor (every workgroup keeps the same value)
     if constexpr (!BEST) {
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         if (C > 1) {
             if (wave == 0) {
                 ClCand none{0.0, kNoKey, 0u};
-                const bool okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, none, a.err, a.spin_limit, a.spin_ticks);
+                const bool okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, none, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
                 if (lane == 0) *s_fail = okx ? 0 : 1;
             }
             __syncthreads();
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
-            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks);
+            if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
             xcd = cd;
         } else if (!probe_hit && view.L != 0) {
@@ -1473,7 +1484,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         (void)hipFree(t->d_cl_slots); t->d_cl_slots = nullptr;
         (void)hipFree(t->d_cl_pairtab); t->d_cl_pairtab = nullptr;
         t->cl_ntests = 0;
-        const size_t words = (size_t)B * 2 * C * kClSlotGranules + 2;   // + the error word
+        const size_t words = (size_t)B * 2 * kClCopies * C * kClSlotGranules + 2;   // + the error word
         TSP_HIP_TRY(hipMalloc(&t->d_cl_slots, sizeof(unsigned long long) * words));
         t->cl_slot_words = words;
         TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * words, s));
@@ -1586,6 +1597,10 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.gbox = inst->d_gbox;
     a.pairtab = t->d_cl_pairtab;
     a.slots = t->d_cl_slots;
+    {
+        const int want = TSP_SW(inst, CLUSTER_COPIES, 0);   // 0: by cluster size
+        a.copies = want > 0 ? std::min(want, kClCopies) : (C >= 128 ? kClCopies : 1);
+    }
     a.poss = t->d_pos;
     if (!t->d_cl_stats) {
         TSP_HIP_TRY(hipMalloc(&t->d_cl_stats, sizeof(long long) * (size_t)B * 256 * 4));
