@@ -59,6 +59,55 @@ __global__ __launch_bounds__(64) void k_xchg(u64 *area, int stride, int rounds, 
     if (acc == 12345.678) area[600] = 1;
 }
 
+// 256 workgroups as 256 / S independent clusters of S: consecutive block ids (a cluster spans the XCDs) or the S
+// members from one XCD (block b: XCD b % 8)
+__global__ __launch_bounds__(64) void k_clusters(u64 *area, int S, int same_xcd, int rounds, int *err, int *xmask) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int t, c;
+    if (same_xcd) { const int x = b % 8, j = b / 8; const int per = 32 / S; t = x * per + j / S; c = j % S; }   // S <= 32
+    else { t = b / S; c = b % S; }
+    if (lane == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        atomicOr(xmask + t, 1 << (id & 7));
+    }
+    u64 *base = area + (size_t)t * 2 * 64;   // S <= 64 granules per parity
+    for (int r = 1; r <= rounds; ++r) {
+        u64 *par = base + (r & 1) * 64;
+        if (lane == 0) __hip_atomic_store(par + c, ((u64)r << 32) | (unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            if (lane < S) ok = (__hip_atomic_load(par + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == (u64)r;
+            if (__all(ok)) break;
+            if (++spins > (1u << 17)) { if (lane == 0) *err = 1; return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+void run_clusters(int S, int same_xcd) {
+    u64 *area; int *err, *xmask;
+    const size_t bytes = 8 * 256 * 2 * 64;
+    hipMalloc(&area, bytes); hipMalloc(&err, 4); hipMalloc(&xmask, 4 * 256);
+    hipMemset(err, 0, 4); hipMemset(xmask, 0, 4 * 256);
+    const int rounds = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipMemset(area, 0, bytes);
+        hipEventRecord(e0);
+        k_clusters<<<256, 64>>>(area, S, same_xcd, rounds, err, xmask);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    int h_err = 0, hm[256];
+    hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost); hipMemcpy(hm, xmask, 4 * 256, hipMemcpyDeviceToHost);
+    printf("%3d clusters of %2d, %s: %.3f us per round (XCC mask of cluster 0: 0x%02x, of the last: 0x%02x)%s\n", 256 / S, S, same_xcd ? "one XCD each " : "consecutive ids", 1e3 * best / rounds, hm[0], hm[256 / S - 1], h_err ? "  GAVE UP" : "");
+    hipFree(area); hipFree(err); hipFree(xmask);
+}
+
 template <int SCOPE, int NG = 1>
 void run(const char *name, int stride, int work, int copies = 1, int cstride = 512, int nsleep = 1, int perm = 0) {
     u64 *area; int *xcc, *err;
@@ -86,8 +135,6 @@ void run(const char *name, int stride, int work, int copies = 1, int cstride = 5
 }
 
 int main() {
-    for (int rep = 0; rep < 2; ++rep)
-        for (int perm : {0, 1})
-            for (int copies : {1, 4, 8}) run<__HIP_MEMORY_SCOPE_AGENT, 3>("agent", 1, 0, copies, 4128, 1, perm);
+    for (int S : {2, 4, 8, 16, 32}) { run_clusters(S, 0); run_clusters(S, 1); }
     return 0;
 }

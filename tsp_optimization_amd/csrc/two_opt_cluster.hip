@@ -77,6 +77,7 @@ struct ClusterArgs {
     const int *pairtab;     // sorted: C x ntests group pairs (r << 16 | c, -1 = none), nearest first, dealt in turn
     unsigned long long *slots;   // B x 2 x kClCopies x C x kClSlotGranules
     int copies;                  // copies in use (1 ... kClCopies)
+    int xcd_local;               // block -> (tour, c) keeps a tour's workgroups on one XCD (host: the grid is a multiple of 8 C)
     int *err;
     int n, nid, ng, ntests, C, max_iters, rmin, rmax, rcap, rbs, count_evals;
     // BEST, sorted scan, with a tabu list (two_opt_tabu_list.hpp has the method): stamps, the compact list of the non-zero
@@ -411,7 +412,15 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = a.n, nid = a.nid, ng = a.ng, C = a.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tour = (int)blockIdx.x / C, c = (int)blockIdx.x % C;
+    // Workgroups are dealt to the XCDs in turn (block b: XCD b % 8, tools/ubench/xchg.hip).  Several tours: the C workgroups
+    // of a tour come from ONE XCD when the grid divides that way -- an exchange among 16 workgroups behind one L2 takes
+    // 0.63 us, 0.9 us when they span all eight (a placement hint: any mapping is correct)
+    int tour = (int)blockIdx.x / C, c = (int)blockIdx.x % C;
+    if (a.xcd_local) {
+        const int x = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        tour = x * ((int)gridDim.x / 8 / C) + j / C;
+        c = j % C;
+    }
     using SR = ClStage<CT>;
     const ClLayout L = cl_layout(n, nid, ng, sizeof(CT), SORTED, a.stage_pairs, FS);
     CT *coord = reinterpret_cast<CT *>(smem + L.coord);
@@ -1609,6 +1618,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.stats_part = t->d_cl_stats;
     a.err = reinterpret_cast<int *>(t->d_cl_slots + (t->cl_slot_words - 2));
     a.n = n; a.ng = inst->ng; a.ntests = t->cl_ntests; a.C = C;
+    a.xcd_local = (B > 1 && C <= 32 && (B * C) % (8 * C) == 0 && TSP_SW(inst, CLUSTER_XCD_LOCAL, 1)) ? 1 : 0;
     a.count_evals = t->count_evals;
     a.tabu = nullptr; a.tabu_list = nullptr; a.tabu_list_n = nullptr; a.tabu_list_cap = 0; a.iter = iter; a.tenure = tenure; a.tabu_side = nullptr;
     if (tabu) {   // the caller has brought the handle's list up to date (tsp_tabu_list_prepare) and zeroed the side words
