@@ -42,4 +42,10 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         nb = int(used.sum())
         print('  inside the scan (thread 0, mean over workgroups): stage+culling %.2f  (-) %.2f  rows+queues %.2f us/step (the rest: final barrier); live rows per workgroup and step %.1f'
               % (cnt[0] / 100.0 / steps / nb, cnt[1] / 100.0 / steps / nb, cnt[2] / 100.0 / steps / nb, cnt[3] / steps / nb))
+        cyc = (C.c_ulonglong * 8)()
+        L.tsp_dev_debug_cluster_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+        L.tsp_dev_debug_cluster_cycles(cyc)
+        turns = max(1, cyc[1])
+        print('  wave 0, rows loop: %.2f turns per step; per turn %.0f cycles fetching items, %.1f units in %.2f trips of %.0f cycles each, %.0f cycles in full tier-1/2 passes'
+              % (turns / steps / nb, cyc[0] / turns, cyc[2] / turns, cyc[4] / turns, cyc[3] / max(1, cyc[4]), cyc[5] / turns))
         print('  wave 0: tier-1/2 passes per step %.2f with %.1f pairs each' % (cnt[4] / steps / nb, cnt[5] / max(1, cnt[4])))

@@ -58,6 +58,7 @@ using gi32c = __attribute__((address_space(1))) int;
 // workgroup of tour 0, in a buffer nothing else reads (cdna_hip_programming.md section 7, in-kernel stamps).
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_cl_prof[256][8];
+__device__ unsigned long long g_cl_cyc[8];   // wave 0 of every workgroup, rows loop: cycles fetching items, turns, units, cycles in the unit loop, unit-loop trips, cycles in dense(64)
 __device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: units, live rows, row quads, tier-1 blocks, tier-2 pairs, survivors
 #define CL_T(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
 #else
@@ -157,7 +158,7 @@ __host__ __device__ inline size_t cl_align16(size_t x) { return (x + 15) & ~(siz
 struct ClLayout {
     size_t coord, order, pos, gbox, gmax, stage, list, items, queue, rows, scratch, total;
 };
-constexpr int kClMaxStagePairs = 8;
+constexpr int kClMaxStagePairs = 8;   // <= kClWaves: one wave stages one pair
 __host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted, int stage_pairs, bool tiles_too = false) {
     ClLayout L;
     size_t o = 0;
@@ -171,7 +172,7 @@ __host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coo
         L.gmax = o; o = cl_align16(o + sizeof(double) * (size_t)ng);
         L.stage = o; o = cl_align16(o + rec * 128 * (size_t)stage_pairs);
         L.list = o; o = cl_align16(o + sizeof(int) * kClListCap);
-        L.items = o; o = cl_align16(o + sizeof(unsigned short) * 64 * (size_t)stage_pairs);
+        L.items = o; o = cl_align16(o + sizeof(unsigned short) * 256 * (size_t)stage_pairs);   // (row, quarter) units: at most 4 per staged row
         L.queue = o; o = cl_align16(o + sizeof(unsigned) * kClQueue * kClWaves);
         if (tiles_too) { L.rows = o; o = cl_align16(o + sizeof(NodeRec) * kClRows); }   // first improvement: both scans
     } else {
@@ -236,6 +237,32 @@ __device__ __forceinline__ int cl_div(int a, int b) {
     if (q * b > a) --q;
     if ((q + 1) * b <= a) ++q;
     return q;
+}
+
+// min / max over each row of 16 lanes (DPP: xor 1, xor 2, half-row mirror, row mirror), every lane of the row gets it
+template <int CTRL> __device__ __forceinline__ float cl_dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ double cl_dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float cl_min2(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double cl_min2(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ float cl_max2(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double cl_max2(double a, double b) { return fmax(a, b); }
+template <typename T> __device__ __forceinline__ T cl_row16_min(T v) {
+    v = cl_min2(v, cl_dpp_mov<0xB1>(v)); v = cl_min2(v, cl_dpp_mov<0x4E>(v)); v = cl_min2(v, cl_dpp_mov<0x141>(v)); v = cl_min2(v, cl_dpp_mov<0x140>(v));
+    return v;
+}
+template <typename T> __device__ __forceinline__ T cl_row16_max(T v) {
+    v = cl_max2(v, cl_dpp_mov<0xB1>(v)); v = cl_max2(v, cl_dpp_mov<0x4E>(v)); v = cl_max2(v, cl_dpp_mov<0x141>(v)); v = cl_max2(v, cl_dpp_mov<0x140>(v));
+    return v;
+}
+template <typename T> __device__ __forceinline__ T cl_readlane(T v, int l);
+template <> __device__ __forceinline__ float cl_readlane<float>(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+template <> __device__ __forceinline__ double cl_readlane<double>(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
 // max over the 64 lanes of a non-negative double (orders like its bits)
@@ -722,29 +749,60 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         if (tid == 0) *s_nitems = 0;
                         __syncthreads();
                     }
-                    for (int x = tid; x < ne * 128; x += kClThreads) {   // whole waves: ne * 128 is a multiple of 64
-                        const int pe = x >> 7;
+                    if (wave < ne) {   // one wave per staged pair (ne <= kClMaxStagePairs <= kClWaves): both groups' records, lane = slot
+                        const int pe = wave;
                         const int e = s_list[e0 + pe];
-                        const bool row_side = ((x >> 6) & 1) == 0;
-                        const int cgp = e & 0xffff;
-                        const int g = row_side ? (e >> 16) : cgp;
-                        const int v = g * 64 + (x & 63);
-                        NodeRec rec;
-                        rec.x = rec.y = rec.xs = rec.ys = 1e30; rec.ds = 0.0; rec.succ = -1; rec.id = -1;   // padding: far from everything
-                        if (v < n) rec = cl_node_v<WT, INT, CT>(coord, order, pos, n, v, view);
-                        stage[x] = SR::pack(rec);
-                        if (row_side) {   // wave-uniform
-                            const double4 cb = gbox[cgp];
-                            const double gx = fmax(0.0, fmax(cb.x - rec.x, rec.x - cb.y)), gy = fmax(0.0, fmax(cb.z - rec.y, rec.y - cb.w));
-                            const double T = rec.ds + gmax[cgp] + prune2 + (BEST ? b0 : 0.0);
-                            const bool reach = (a.dbg & 2) ? v < n : (T > 0.0 && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T));
-                            const unsigned long long m = __ballot(reach);
-                            if (m) {
-                                int base = 0;
-                                if (lane == 0) base = atomicAdd(s_nitems, __popcll(m));
-                                base = __builtin_amdgcn_readfirstlane(base);
-                                if (reach) s_items[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)x;
+                        const int rg = e >> 16, cgp = e & 0xffff;
+                        const int vr = rg * 64 + lane, vc = cgp * 64 + lane;
+                        NodeRec rr, rc;
+                        rr.x = rr.y = rr.xs = rr.ys = 1e30; rr.ds = 0.0; rr.succ = -1; rr.id = -1;   // padding: far from everything
+                        rc = rr;
+                        if (vr < n) rr = cl_node_v<WT, INT, CT>(coord, order, pos, n, vr, view);
+                        if (vc < n) rc = cl_node_v<WT, INT, CT>(coord, order, pos, n, vc, view);
+                        stage[(2 * pe) * 64 + lane] = SR::pack(rr);
+                        stage[(2 * pe + 1) * 64 + lane] = SR::pack(rc);
+                        // The columns' four quarters (16 consecutive slots: neighbours on the curve): box and longest successor edge,
+                        // from the records just derived (row reductions of 16 lanes).  A row is tested against each quarter -- not
+                        // against the whole group's box with the group's persistent bound: 62 % fewer lanes reach tier 0 -- and its
+                        // item carries the quarters it can reach.
+                        using QT = std::conditional_t<SR::kF32, float, double>;   // float replica: coordinates and lengths are exact floats
+                        const bool creal = vc < n;
+                        const QT qx0 = cl_row16_min<QT>(creal ? (QT)rc.x : (QT)1e30), qx1 = cl_row16_max<QT>(creal ? (QT)rc.x : (QT)-1e30);
+                        const QT qy0 = cl_row16_min<QT>(creal ? (QT)rc.y : (QT)1e30), qy1 = cl_row16_max<QT>(creal ? (QT)rc.y : (QT)-1e30);
+                        const QT qdm = cl_row16_max<QT>(creal ? (QT)rc.ds : (QT)0);
+                        unsigned qm = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const QT x0 = cl_readlane<QT>(qx0, 16 * k), x1 = cl_readlane<QT>(qx1, 16 * k);
+                            const QT y0 = cl_readlane<QT>(qy0, 16 * k), y1 = cl_readlane<QT>(qy1, 16 * k), dm = cl_readlane<QT>(qdm, 16 * k);
+                            bool reach;
+                            if constexpr (SR::kF32) {   // as tier 0 below: the rounding of the squares paid for in slack, T taken 2 units high
+                                const float rx = (float)rr.x, ry = (float)rr.y;
+                                const float gx = fmaxf(0.f, fmaxf(x0 - rx, rx - x1)), gy = fmaxf(0.f, fmaxf(y0 - ry, ry - y1));
+                                const float T = (float)rr.ds + dm + (float)((BEST ? b0 : 0.0) + prune2 + 2.0);
+                                reach = fmaf(gx, gx, gy * gy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
+                            } else {
+                                const double gx = fmax(0.0, fmax(x0 - rr.x, rr.x - x1)), gy = fmax(0.0, fmax(y0 - rr.y, rr.y - y1));
+                                const double T = rr.ds + dm + prune2 + (BEST ? b0 : 0.0);
+                                reach = T > 0.0 && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
                             }
+                            qm |= (reach ? 1u : 0u) << k;
+                        }
+                        if (a.dbg & 2) qm = vr < n ? 0xfu : 0u;
+                        // units: (row, quarter) pairs, quarter-major within this wave's share of the list; a unit is the row's stage
+                        // slot (10 bits), the quarter (2), "the pair is a group with itself" (1)
+                        const unsigned long long m0 = __ballot(qm & 1u), m1 = __ballot(qm & 2u), m2 = __ballot(qm & 4u), m3 = __ballot(qm & 8u);
+                        const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+                        if (c0 + c1 + c2 + c3) {
+                            int base = 0;
+                            if (lane == 0) base = atomicAdd(s_nitems, c0 + c1 + c2 + c3);
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            const unsigned long long below = (1ull << lane) - 1ull;
+                            const unsigned u = (unsigned)((2 * pe) * 64 + lane) | (rg == cgp ? 1u << 14 : 0u);
+                            if (qm & 1u) s_items[base + __popcll(m0 & below)] = (unsigned short)u;
+                            if (qm & 2u) s_items[base + c0 + __popcll(m1 & below)] = (unsigned short)(u | (1u << 10));
+                            if (qm & 4u) s_items[base + c0 + c1 + __popcll(m2 & below)] = (unsigned short)(u | (2u << 10));
+                            if (qm & 8u) s_items[base + c0 + c1 + c2 + __popcll(m3 & below)] = (unsigned short)(u | (3u << 10));
                         }
                     }
                     __syncthreads();
@@ -810,60 +868,64 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             if (tid == 0) { prof[6] += 1; prof[7] += cnt; }
 #endif
                         };
-                        constexpr int RU = 4;   // rows in flight per wave: their LDS reads are issued together (2 and 8 measure the same: 15.9 ms per descent)
-                        for (int k0 = wave * RU; k0 < nit; k0 += kClWaves * RU) {
-                            int ridx[RU], cidx[RU], ee[RU];
-                            bool valid[RU], need[RU];
+                        // The units, 16 per wave and turn (one per 16 lanes and trip, four trips whose LDS reads are issued together);
+                        // every wave takes one contiguous share of the list
+                        constexpr int TR = 4;
+                        const int g = lane >> 4, l15 = lane & 15;
+                        const int per = ((nit + kClWaves * 16 - 1) / (kClWaves * 16)) * 16;
+                        const int uend = min(nit, (wave + 1) * per);
+                        for (int u0 = wave * per; u0 < uend; u0 += 16) {
+                            w_lane += 16 * min(16, uend - u0);
+                            int un[TR];
 #pragma unroll
-                            for (int qq = 0; qq < RU; ++qq) {
-                                valid[qq] = k0 + qq < nit;
-                                ridx[qq] = (int)s_items[min(k0 + qq, nit - 1)];
+                            for (int t = 0; t < TR; ++t) {
+                                const int ui = u0 + 4 * t + g;
+                                un[t] = ui < uend ? (int)s_items[ui] : -1;
                             }
-                            w_lane += 64 * min(RU, nit - k0);
+                            int ridx[TR], cidx[TR];
+                            bool need[TR];
 #pragma unroll
-                            for (int qq = 0; qq < RU; ++qq) {
-                                const int pe = ridx[qq] >> 7;
-                                ee[qq] = s_list[e0 + pe];
-                                cidx[qq] = (2 * pe + 1) * 64 + lane;
+                            for (int t = 0; t < TR; ++t) {
+                                const int uu = max(un[t], 0);
+                                ridx[t] = uu & 1023;
+                                cidx[t] = (ridx[t] & ~127) + 64 + (((uu >> 10) & 3) << 4) + l15;
                             }
-                            // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin; the row's x, y and edge
-                            // length are a wave-uniform LDS read (broadcast), the column's one read per lane
+                            // tier 0, the new edge (a, b) alone: |ab| < bound + d(a,a1) + d(b,b1) + margin
                             if constexpr (SR::kF32) {
                                 // integer coordinates (exact as floats): a float test with its rounding paid for in slack -- s may
                                 // come out low by 2^-22 relative, T (< 2^23) is taken 2 units high; half the issue cost of fp64
-                                float rx[RU], ry[RU], rd[RU], cxf[RU], cyf[RU], cdf[RU];
+                                float rx[TR], ry[TR], rd[TR], cxf[TR], cyf[TR], cdf[TR];
 #pragma unroll
-                                for (int qq = 0; qq < RU; ++qq) {
-                                    SR::xydf(stage[ridx[qq]], rx[qq], ry[qq], rd[qq]);
-                                    SR::xydf(stage[cidx[qq]], cxf[qq], cyf[qq], cdf[qq]);
+                                for (int t = 0; t < TR; ++t) {
+                                    SR::xydf(stage[ridx[t]], rx[t], ry[t], rd[t]);
+                                    SR::xydf(stage[cidx[t]], cxf[t], cyf[t], cdf[t]);
                                 }
                                 const float bf = (float)((BEST ? bd : 0.0) + prune2 + 2.0);
 #pragma unroll
-                                for (int qq = 0; qq < RU; ++qq) {
-                                    const float dx = rx[qq] - cxf[qq], dy = ry[qq] - cyf[qq], T = rd[qq] + cdf[qq] + bf;
-                                    need[qq] = fmaf(dx, dx, dy * dy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
+                                for (int t = 0; t < TR; ++t) {
+                                    const float dx = rx[t] - cxf[t], dy = ry[t] - cyf[t], T = rd[t] + cdf[t] + bf;
+                                    need[t] = fmaf(dx, dx, dy * dy) < (ATT10 ? 10.0f : 1.0f) * 1.000002f * T * fabsf(T);   // T <= 0: never
                                 }
                             } else {
-                                double rx[RU], ry[RU], rd[RU], cx[RU], cy[RU], cd[RU];
+                                double rx[TR], ry[TR], rd[TR], cx[TR], cy[TR], cd[TR];
 #pragma unroll
-                                for (int qq = 0; qq < RU; ++qq) {
-                                    SR::xyd(stage[ridx[qq]], rx[qq], ry[qq], rd[qq]);
-                                    SR::xyd(stage[cidx[qq]], cx[qq], cy[qq], cd[qq]);
+                                for (int t = 0; t < TR; ++t) {
+                                    SR::xyd(stage[ridx[t]], rx[t], ry[t], rd[t]);
+                                    SR::xyd(stage[cidx[t]], cx[t], cy[t], cd[t]);
                                 }
 #pragma unroll
-                                for (int qq = 0; qq < RU; ++qq) {
-                                    const double dx = rx[qq] - cx[qq], dy = ry[qq] - cy[qq], T = rd[qq] + cd[qq] + (BEST ? bd : 0.0) + prune2;
-                                    need[qq] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);
+                                for (int t = 0; t < TR; ++t) {
+                                    const double dx = rx[t] - cx[t], dy = ry[t] - cy[t], T = rd[t] + cd[t] + (BEST ? bd : 0.0) + prune2;
+                                    need[t] = fma(dx, dx, dy * dy) < (ATT10 ? 10.0 : 1.0) * T * fabs(T);
                                 }
                             }
 #pragma unroll
-                            for (int qq = 0; qq < RU; ++qq) {
-                                // one slot pair once (inside a group: row slot below column slot); padding columns never
-                                const int r = ee[qq] >> 16, cgp = ee[qq] & 0xffff;
-                                const bool nd = need[qq] & valid[qq] & (cgp * 64 + lane < n) & ((cgp > r) | ((ridx[qq] & 63) < lane));
+                            for (int t = 0; t < TR; ++t) {
+                                // one slot pair once (inside a group: row slot below column slot); padding columns lie 1e30 away
+                                const bool nd = need[t] & (un[t] >= 0) & (!((un[t] >> 14) & 1) | ((ridx[t] & 63) < (cidx[t] & 63)));
                                 const unsigned long long m = __ballot(nd);
                                 if (m) {
-                                    if (nd) q[(qtail + __popcll(m & ((1ull << lane) - 1ull))) & (kClQueue - 1)] = (unsigned)ridx[qq] | ((unsigned)cidx[qq] << 16);
+                                    if (nd) q[(qtail + __popcll(m & ((1ull << lane) - 1ull))) & (kClQueue - 1)] = (unsigned)ridx[t] | ((unsigned)cidx[t] << 16);
                                     qtail += __popcll(m);
                                     w_t1 += __popcll(m);
                                     if (qtail - qhead >= 64) dense(64);
@@ -1413,6 +1475,12 @@ extern "C" int tsp_dev_debug_cluster(unsigned long long *out /* 256 x 8 */) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_prof), sizeof(unsigned long long) * 256 * 8) != hipSuccess) return -1;
     static unsigned long long z[256 * 8];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_prof), z, sizeof z);
+    return 0;
+}
+extern "C" int tsp_dev_debug_cluster_cycles(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_cl_cyc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_cyc), z, sizeof z);
     return 0;
 }
 extern "C" int tsp_dev_debug_cluster_counts(unsigned long long *out8) {
