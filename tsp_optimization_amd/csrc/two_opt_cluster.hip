@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if constexpr (SORTED) {
         for (int g = tid; g < ng; g += kClThreads) gbox[g] = ClCoord<CT>::box(a.gbox[g], a.org_x, a.org_y);
     }
-    if (tid == 0) *s_fail = 0;
+    if (tid == 0) { *s_fail = 0; *s_nitems = 0; }
     int ci = st->ci, cj = st->cj, chunk = min(max(st->chunk_rows, 1), a.rmax), done = 0;
     int hit_rows = st->hit_rows;   // FIRST: running mean of the rows between hits (kept from call to call: HEU_VNS's rounds look alike)
     // caller's node id <-> id inside the replica (the same thing unless the replica is in rank order)
@@ -546,8 +546,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     // the workgroup's share of the group-pair table never changes: when it fits one round of box tests (one entry per
     // thread) it is read once, not once per step (a global load at the head of every step's critical path otherwise)
     int tab_reg = -1;
+    // ... and when it fits ONE WAVE (n = 10 000 on 256 workgroups: 49 group pairs each), every wave runs all the tests itself on
+    // the same numbers: the survivors are a ballot in every wave's registers -- no compaction through LDS, no barrier between the
+    // tests and the staging of the survivors
+    const bool tests_per_wave = SORTED && a.ntests <= 64;
     if constexpr (SORTED) {
-        if (a.ntests <= kClThreads && tid < a.ntests) tab_reg = a.pairtab[(size_t)c * a.ntests + tid];
+        if (tests_per_wave) { if (lane < a.ntests) tab_reg = a.pairtab[(size_t)c * a.ntests + lane]; }
+        else if (a.ntests <= kClThreads && tid < a.ntests) tab_reg = a.pairtab[(size_t)c * a.ntests + tid];
     }
     // executed work, per wave (wave-uniform values): rows or row-lanes through tier 0, pairs queued for tier 1, delta
     // expressions, staged records; summed into the tour's control block at the end of the launch
@@ -707,6 +712,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             int m0 = 0;
             while (m0 < a.ntests) {
                 int kept = 0;
+                unsigned long long wave_surv = 0ull;   // tests_per_wave: the surviving entries of tab_reg, by lane
                 while (m0 < a.ntests && kept + kClThreads <= kClListCap) {
                     const int m = m0 + tid;
                     const int e = a.ntests <= kClThreads ? tab_reg : (m < a.ntests ? tab[m] : -1);
@@ -718,6 +724,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         const double T = gmax[r] + gmax[cg] + prune2 + (BEST ? b0 : 0.0);   // b0: what is known about this sweep before it starts
                         surv = T > 0.0 && gx * gx + gy * gy < (ATT10 ? 10.0 * T * T : T * T);
                         if (a.dbg & 4) surv = true;
+                    }
+                    if (tests_per_wave) {   // (the list's counter was zeroed behind the arg-min barrier of the step before)
+                        wave_surv = __ballot(surv);
+                        kept = __popcll(wave_surv);
+                        m0 = a.ntests;
+                        break;
                     }
                     const unsigned long long bal = __ballot(surv);
                     if (lane == 0) s_wcount[wave] = __popcll(bal);
@@ -751,7 +763,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     }
                     if (wave < ne) {   // one wave per staged pair (ne <= kClMaxStagePairs <= kClWaves): both groups' records, lane = slot
                         const int pe = wave;
-                        const int e = s_list[e0 + pe];
+                        int e;
+                        if (tests_per_wave) {   // the (e0 + pe)-th survivor of this wave's own ballot
+                            unsigned long long mm = wave_surv;
+                            for (int i = 0; i < e0 + pe; ++i) mm &= mm - 1ull;
+                            e = __builtin_amdgcn_readlane(tab_reg, __builtin_ctzll(mm));
+                        } else {
+                            e = s_list[e0 + pe];
+                        }
                         const int rg = e >> 16, cgp = e & 0xffff;
                         const int vr = rg * 64 + lane, vc = cgp * 64 + lane;
                         NodeRec rr, rc;
@@ -869,13 +888,15 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 #endif
                         };
                         // The units, 16 per wave and turn (one per 16 lanes and trip, four trips whose LDS reads are issued together);
-                        // every wave takes one contiguous share of the list
-                        constexpr int TR = 4;
+                        // turns dealt to the waves in turn
+#ifndef TSP_CL_TR
+#define TSP_CL_TR 2
+#endif
+                        constexpr int TR = TSP_CL_TR;
                         const int g = lane >> 4, l15 = lane & 15;
-                        const int per = ((nit + kClWaves * 16 - 1) / (kClWaves * 16)) * 16;
-                        const int uend = min(nit, (wave + 1) * per);
-                        for (int u0 = wave * per; u0 < uend; u0 += 16) {
-                            w_lane += 16 * min(16, uend - u0);
+                        for (int u0 = wave * 4 * TR; u0 < nit; u0 += kClWaves * 4 * TR) {
+                            const int uend = min(nit, u0 + 4 * TR);
+                            w_lane += 16 * (uend - u0);
                             int un[TR];
 #pragma unroll
                             for (int t = 0; t < TR; ++t) {
@@ -1081,6 +1102,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (lane == 0) { s_d[wave] = bd; s_k[wave] = key; s_ip[wave] = ipair; }
         }
         if (!probe_hit) __syncthreads();
+        if (tests_per_wave && tid == kClThreads - 1) *s_nitems = 0;   // the next sorted scan's unit counter (its last readers are behind the barrier above, its next writers behind the exchange's)
         CL_T(2);
         if (wave == 0 && !probe_hit) {
             double d = 0.0;
