@@ -599,7 +599,7 @@ def main():
             "frac": ops / (kms * 1e-3) / FP64_LANE_OPS_PEAK, "unit": "T lane-op/s",
             "reference_equivalent_evals_per_s": stf["evals"] / (kms * 1e-3),
             "sweep_that_finds_nothing_us_per_call": 1e6 * float(np.mean(t_nohit[2:])),
-            "note": "a chain of 2 704 dependent moves: 6.9 us per step, 3.8 of it one all-to-all exchange (DESIGN.md 4.8)"}
+            "note": "a chain of 2 704 dependent moves: 5.8 us per step, 3.1 of it one all-to-all exchange (DESIGN.md 4.8)"}
 
     if rank == 0:
         guarded("roofline", roofline_section)
