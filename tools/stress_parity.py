@@ -19,7 +19,7 @@ def run(seed, cases, ctx=None, verbose=True, max_n=3000):
     finally:
         if prev is None: os.environ.pop("TSP_SORTED_MIN_N", None)
         else: os.environ["TSP_SORTED_MIN_N"] = prev
-        for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE", "TSP_CLUSTER_FIRST_SORTED", "TSP_CLUSTER_FS_ROWS"): os.environ.pop(k, None)
+        for k in ("TSP_CLUSTER_BLOCKS", "TSP_LDS_PROBE", "TSP_CLUSTER_FIRST_SORTED", "TSP_CLUSTER_FS_ROWS", "TSP_CLUSTER_COPIES", "TSP_CLUSTER_XCD_LOCAL"): os.environ.pop(k, None)
 
 
 FAILED_AT = []
@@ -76,6 +76,7 @@ def _run(seed, cases, ctx, verbose, max_n):
         fsr = int(rng.choice([-1, 0, 1, 3, 60]))
         os.environ["TSP_CLUSTER_FIRST_SORTED"] = "0" if fsr < 0 else "8"
         os.environ["TSP_CLUSTER_FS_ROWS"] = str(max(fsr, 0))
+        os.environ["TSP_CLUSTER_COPIES"] = str(int(rng.choice([0, 1, 2, 3, 8])))   # copies of the exchange area
         inst.reload_switches()
         if n <= 300:
             rc, s, o, st = inst.two_opt(tour, cost, mode=E.BEST, engine=3)
@@ -83,6 +84,7 @@ def _run(seed, cases, ctx, verbose, max_n):
         rc, s, o, st = inst.two_opt(tour, cost, mode=E.FIRST, engine=3)
         ok = _chk(ok, 75, (s == fs).all() and o == fo and (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (fst["sweeps"], fst["evals"], fst["moves"], fst["reversed"]))
         del os.environ["TSP_CLUSTER_BLOCKS"]
+        del os.environ["TSP_CLUSTER_COPIES"]
         inst.reload_switches()
         if n <= 8000:   # the LDS engine (one workgroup per tour), first improvement, with and without the probe
             os.environ["TSP_LDS_PROBE"] = str(int(rng.choice([0, 1, 600, 1 << 30])))
@@ -108,16 +110,19 @@ def _run(seed, cases, ctx, verbose, max_n):
             ok = _chk(ok, 99, (tb.download() == exp).all() and tb.list_info()[1])
             tb.close()
         if c % 3 == 0 and n >= 8:
-            # a batch of three tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
-            t3 = np.stack([random_tour(n, rng) for _ in range(3)])
+            # a batch of three or eight tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
+            nt = 8 if n <= 200 else 3   # eight tours: the grid divides by XCD (a tour's workgroups from one XCD)
+            t3 = np.stack([random_tour(n, rng) for _ in range(nt)])
             c3 = np.array([O.succ_cost(xy, wt, t, integer_cost=ic) for t in t3])
             rc, s3, o3, st3 = inst.two_opt(t3, c3, mode=E.FIRST)
-            os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 7, 33, 85])))
+            os.environ["TSP_CLUSTER_BLOCKS"] = str(int(rng.choice([1, 2, 7, 33, 85] if nt == 3 else [1, 2, 7, 16, 32])))   # whole clusters must be resident
+            os.environ["TSP_CLUSTER_XCD_LOCAL"] = str(int(rng.integers(0, 2)))
             inst.reload_switches()
-            rc, s4, o4, st4 = inst.two_opt(t3, c3, mode=E.FIRST, engine=3)      # three clusters side by side
+            rc, s4, o4, st4 = inst.two_opt(t3, c3, mode=E.FIRST, engine=3)      # clusters side by side
             del os.environ["TSP_CLUSTER_BLOCKS"]
+            del os.environ["TSP_CLUSTER_XCD_LOCAL"]
             inst.reload_switches()
-            for b in range(3):
+            for b in range(nt):
                 _, fs3, fo3, fst3, _ = O.two_opt_first(xy, wt, t3[b], c3[b], integer_cost=ic)
                 ok = _chk(ok, 113, (s3[b] == fs3).all() and o3[b] == fo3 and st3[b]["evals"] == fst3["evals"])
                 ok = _chk(ok, 114, (s4[b] == fs3).all() and o4[b] == fo3 and st4[b]["evals"] == fst3["evals"])

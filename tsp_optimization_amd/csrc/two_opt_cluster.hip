@@ -159,6 +159,7 @@ struct ClLayout {
     size_t coord, order, pos, gbox, gmax, stage, list, items, queue, rows, scratch, total;
 };
 constexpr int kClMaxStagePairs = 8;   // <= kClWaves: one wave stages one pair
+static_assert(kClMaxStagePairs <= kClWaves && kClMaxStagePairs * 128 <= 1024, "one wave per staged pair; a unit holds a 10-bit stage slot");
 __host__ __device__ inline ClLayout cl_layout(int n, int nid, int ng, size_t coord_elem, bool sorted, int stage_pairs, bool tiles_too = false) {
     ClLayout L;
     size_t o = 0;
