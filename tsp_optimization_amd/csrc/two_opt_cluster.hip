@@ -470,6 +470,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     u64 *s_win_k = reinterpret_cast<u64 *>(scratch + 456);
     unsigned *s_win_ip = reinterpret_cast<unsigned *>(scratch + 464);
     int *s_fail = reinterpret_cast<int *>(scratch + 468);
+    int *s_vote = reinterpret_cast<int *>(scratch + 472);   // tiles scan, first improvement: the stamp of the last vote that saw a hit
     static_assert(kClWaves <= 8, "scratch carve-up: eight wave winners");
     unsigned *s_ip = reinterpret_cast<unsigned *>(scratch + 480);      // 8: the waves' winners (internal pairs)
     double *s_b0 = reinterpret_cast<double *>(scratch + 256 + 15 * 8);  // the next sweep's bound (s_ll[15]: block sums use 0 .. 7, the final counters come after the loop)
@@ -509,7 +510,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if constexpr (SORTED) {
         for (int g = tid; g < ng; g += kClThreads) gbox[g] = ClCoord<CT>::box(a.gbox[g], a.org_x, a.org_y);
     }
-    if (tid == 0) { *s_fail = 0; *s_nitems = 0; }
+    if (tid == 0) { *s_fail = 0; *s_nitems = 0; *s_vote = 0; }
+    int vote_seq = 0;
     int ci = st->ci, cj = st->cj, chunk = min(max(st->chunk_rows, 1), a.rmax), done = 0;
     int hit_rows = st->hit_rows;   // FIRST: running mean of the rows between hits (kept from call to call: HEU_VNS's rounds look alike)
     // caller's node id <-> id inside the replica (the same thing unless the replica is in rank order)
@@ -1085,7 +1087,15 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 }
                 CL_T(10);
                 if constexpr (!BEST) {
-                    if (!any_hit && __syncthreads_or(key != kNoKey)) { any_hit = true; hit_rb = rbi; }
+                    // has anybody here found an improving pair?  Then this workgroup's later row blocks are skipped.  Asked only when
+                    // there is a later tile, and through one flag word and one barrier (a stamp no earlier vote has used: no zeroing)
+                    if (!any_hit && t + C < nrb * nb) {
+                        const int stamp = ++vote_seq;
+                        const bool anyh = __any(key != kNoKey);
+                        if (lane == 0 && anyh) *s_vote = stamp;
+                        __syncthreads();
+                        if (*s_vote == stamp) { any_hit = true; hit_rb = rbi; }
+                    }
                 }
             }
         }

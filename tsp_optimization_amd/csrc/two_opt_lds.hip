@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
     double *s_chunk = reinterpret_cast<double *>(scratch + 384);  // 64 doubles (fcost cost recompute)
     int4 *s_win = reinterpret_cast<int4 *>(scratch + 384);        // 8 (FIRST, the probe's vote): shares the chunk, which only BEST uses
     int *s_flag = reinterpret_cast<int *>(scratch + 384 + 384);   // FIRST: second probe round
+    int *s_vote = reinterpret_cast<int *>(scratch + 384 + 384 + 8);   // FIRST, scan: two words, the stamp of the last vote (by parity) that saw a hit in the block's first row
     float4 *s_rowsf = reinterpret_cast<float4 *>(scratch + 1024);  // x, y (relative to the instance corner), edge length of the block's rows as floats
     // Integer coordinates of bounded span are exact as floats relative to the instance corner: the new-edge bound runs in fp32
     // first (its rounding paid for in slack: s may come out 2^-22 low, T -- below 2^23 -- is taken 2 units high), four rows per
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
         return block_sum<long long>(cnt, s_ll);
     };
     long long r_cur = pair_rank(ci, cj, n);     // rank of the cursor in scan order
+    int vote_seq = 0;
+    if (tid < 2) s_vote[tid] = 0;
     __syncthreads();
     if constexpr (MODE == TSP_2OPT_FIRST) {
         if (count_evals && (ci != 0 || cj != 0)) { adjA0 = edges_upto(make_key(ci, cj)); sweep_open = true; }
@@ -448,12 +451,29 @@ __global__ __launch_bounds__(kLdsThreads) void k_lds_two_opt(const double2 *__re
 #ifdef TSP_STAMPS
                 const unsigned long long q2 = clock64();
                 bool stop = false;
-                if constexpr (MODE == TSP_2OPT_FIRST) { if (vote) stop = __syncthreads_or(key != kNoKey && key_i(key) == rb); }
+                if constexpr (MODE == TSP_2OPT_FIRST) {
+                    if (vote) {
+                        const int stamp = ++vote_seq;
+                        const bool anyh = __any(key != kNoKey && key_i(key) == rb);
+                        if ((tid & 63) == 0 && anyh) s_vote[stamp & 1] = stamp;
+                        __syncthreads();
+                        stop = s_vote[stamp & 1] == stamp;
+                    }
+                }
                 if (tour == 0 && tid == 0) { const unsigned long long q3 = clock64(); scn[0] += q1 - q0; scn[1] += q2 - q1; scn[2] += q3 - q2; scn[3] += 1; scn[4] += nr; }
                 if (stop) break;
 #else
                 if constexpr (MODE == TSP_2OPT_FIRST) {
-                    if (vote && __syncthreads_or(key != kNoKey && key_i(key) == rb)) break;
+                    // The vote: a hit in the block's first row ends the search.  One flag word and one barrier (__syncthreads_or is a
+                    // workgroup reduction: several); the word holds the stamp of the last vote that saw a hit -- no zeroing -- and
+                    // votes alternate between two words: nobody writes vote k + 2 before everybody has read vote k.
+                    if (vote) {
+                        const int stamp = ++vote_seq;
+                        const bool anyh = __any(key != kNoKey && key_i(key) == rb);
+                        if ((tid & 63) == 0 && anyh) s_vote[stamp & 1] = stamp;
+                        __syncthreads();
+                        if (s_vote[stamp & 1] == stamp) break;
+                    }
                 }
 #endif
             }
