@@ -77,10 +77,12 @@ def test_best_improvement_rand10000_properties(eng, ctx):
     inst.close()
 
 
-@pytest.mark.parametrize("n,integer_coords", [(20011, True), (12007, False)])
+@pytest.mark.parametrize("n,integer_coords", [(20011, True), (12007, False), (11003, True), (6007, False)])
 def test_large_odd_sizes_prefix_of_both_trajectories(eng, ctx, n, integer_coords):
     """Sizes beyond the BASELINE configs (odd n, tiles that do not divide, general and integer-coordinate
-    variants): the first best-improvement sweeps and the first first-improvement moves equal the oracle's."""
+    variants): the first best-improvement sweeps and the first first-improvement moves equal the oracle's.  11 003 and 6 007 still
+    fit the CLUSTER engine's sorted scan, with room for four or five staged group pairs instead of eight (several rounds of
+    staging per step)."""
     rng = np.random.default_rng(n)
     xy = rng.integers(0, 700_000, size=(n, 2)).astype(np.float64)
     if not integer_coords:
