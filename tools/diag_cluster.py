@@ -33,7 +33,20 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         col = a[used, k] / 100.0 / steps
         print('  %-22s mean %6.2f  min %6.2f  max %6.2f us/step' % (names[k], col.mean(), col.min(), col.max()))
     print('  %-22s mean %6.2f us/step' % ('sum', (a[used, :6].sum(1) / 100.0 / steps).mean()))
+    col = a[used, 6] / 100.0 / steps
+    print('  own scan time of a workgroup (staging + units, thread 0), mean over the steps: mean %.2f  min %.2f  p10 %.2f  p90 %.2f  max %.2f us/step' % (col.mean(), col.min(), np.percentile(col, 10), np.percentile(col, 90), col.max()))
     L.tsp_dev_debug_cluster_counts(cnt)
+    ws = (C.c_ulonglong * 1024)()
+    L.tsp_dev_debug_cluster_wstat.argtypes = [C.POINTER(C.c_ulonglong)]
+    L.tsp_dev_debug_cluster_wstat(ws)
+    w = np.array(ws[:], dtype=np.float64).reshape(256, 4)[used] / steps
+    if mode == E.BEST:
+        X = np.column_stack([np.ones(len(col)), w[:, 0] / 16.0, w[:, 1], w[:, 3] / 128.0])
+        beta, *_ = np.linalg.lstsq(X, col, rcond=None)
+        print('  per workgroup and step: units mean %.0f (min %.0f max %.0f), tier-1 pairs mean %.0f (min %.0f max %.0f), staged pairs mean %.2f (min %.2f max %.2f)'
+              % (X[:, 1].mean(), X[:, 1].min(), X[:, 1].max(), X[:, 2].mean(), X[:, 2].min(), X[:, 2].max(), X[:, 3].mean(), X[:, 3].min(), X[:, 3].max()))
+        print('  own scan time ~ %.2f + %.4f units + %.4f tier-1 pairs + %.3f staged pairs (least squares, residual sd %.2f us; correlations %.2f %.2f %.2f)'
+              % (beta[0], beta[1], beta[2], beta[3], (col - X @ beta).std(), np.corrcoef(col, X[:, 1])[0, 1], np.corrcoef(col, X[:, 2])[0, 1], np.corrcoef(col, X[:, 3])[0, 1]))
     if mode == E.FIRST:
         nb = int(used.sum())
         print('  inside the scan (thread 0, mean over workgroups): before tile %.2f  derive+barriers %.2f  row loop %.2f us/step; tiles per workgroup and step %.2f'
@@ -42,10 +55,4 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         nb = int(used.sum())
         print('  inside the scan (thread 0, mean over workgroups): stage+culling %.2f  (-) %.2f  rows+queues %.2f us/step (the rest: final barrier); live rows per workgroup and step %.1f'
               % (cnt[0] / 100.0 / steps / nb, cnt[1] / 100.0 / steps / nb, cnt[2] / 100.0 / steps / nb, cnt[3] / steps / nb))
-        cyc = (C.c_ulonglong * 8)()
-        L.tsp_dev_debug_cluster_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
-        L.tsp_dev_debug_cluster_cycles(cyc)
-        turns = max(1, cyc[1])
-        print('  wave 0, rows loop: %.2f turns per step; per turn %.0f cycles fetching items, %.1f units in %.2f trips of %.0f cycles each, %.0f cycles in full tier-1/2 passes'
-              % (turns / steps / nb, cyc[0] / turns, cyc[2] / turns, cyc[4] / turns, cyc[3] / max(1, cyc[4]), cyc[5] / turns))
         print('  wave 0: tier-1/2 passes per step %.2f with %.1f pairs each' % (cnt[4] / steps / nb, cnt[5] / max(1, cnt[4])))

@@ -58,7 +58,7 @@ using gi32c = __attribute__((address_space(1))) int;
 // workgroup of tour 0, in a buffer nothing else reads (cdna_hip_programming.md section 7, in-kernel stamps).
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_cl_prof[256][8];
-__device__ unsigned long long g_cl_cyc[8];   // wave 0 of every workgroup, rows loop: cycles fetching items, turns, units, cycles in the unit loop, unit-loop trips, cycles in dense(64)
+__device__ unsigned long long g_cl_wstat[256][4];   // per workgroup of tour 0: lane pairs, tier-1 pairs, delta expressions, staged records
 __device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: units, live rows, row quads, tier-1 blocks, tier-2 pairs, survivors
 #define CL_T(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
 #else
@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     }
 
 #ifdef TSP_STAMPS
-    if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][7] += steps - st->steps; }
+    if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][6] += prof[8] + prof[10]; g_cl_prof[c][7] += steps - st->steps; }
     if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
 #endif
     if (!failed) flush_view();   // a reversal the last exchange step left pending
@@ -1371,6 +1371,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             for (int w = 0; w < kClWaves; ++w)
                 tot += tid == 0 ? s_ll[w] : (tid == 1 ? s_ll[8 + w] : (tid == 2 ? (long long)s_k[w] : (long long)s_k[8 + w]));
             a.stats_part[((size_t)tour * 256 + c) * 4 + tid] += tot;
+#ifdef TSP_STAMPS
+            if (tour == 0 && c < 256) g_cl_wstat[c][tid] += (unsigned long long)tot;
+#endif
         }
         __syncthreads();
     }
@@ -1510,10 +1513,10 @@ extern "C" int tsp_dev_debug_cluster(unsigned long long *out /* 256 x 8 */) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_prof), z, sizeof z);
     return 0;
 }
-extern "C" int tsp_dev_debug_cluster_cycles(unsigned long long *out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_cl_cyc), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    unsigned long long z[8] = {0};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_cyc), z, sizeof z);
+extern "C" int tsp_dev_debug_cluster_wstat(unsigned long long *out /* 256 x 4 */) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_wstat), sizeof(unsigned long long) * 256 * 4) != hipSuccess) return -1;
+    static unsigned long long z[256 * 4];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_wstat), z, sizeof z);
     return 0;
 }
 extern "C" int tsp_dev_debug_cluster_counts(unsigned long long *out8) {
