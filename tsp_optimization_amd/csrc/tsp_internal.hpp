@@ -178,8 +178,13 @@ struct tsp_dev_tours {
     // drivers on resident tours: the incumbent kept on the device (tsp_dev_tours_snapshot / _restore), kick results
     int *d_order_snap = nullptr;
     std::vector<double> h_obj_snap;
-    int *d_kick_result = nullptr;
+    int *d_kick_result = nullptr;    // 8 ints: {accepted, a1, b1, 0, acted, improved, 0, 0}
     int *h_kick_result = nullptr;    // pinned
+    // work a driver wants queued right behind the FIRST launch of a CLUSTER run, before the run's wait for the device
+    // (tabu(): incumbent snapshot + kick decided on the device from the finished descent -- one wait per iteration, not two)
+    void (*cl_post)(void *ctx, hipStream_t s, const int *d_err) = nullptr;
+    void *cl_post_ctx = nullptr;
+    bool cl_post_ran = false;
     int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)
     // reset point (device copies of the uploaded tours)

@@ -1785,6 +1785,10 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         t->cl_epoch += ((unsigned)a.max_iters + 5u) & ~1u;   // even: the parity of an epoch picks the half of the area (+1: the arrival rendezvous)
         hipError_t e = hipSuccess;
         TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, on_fs ? pf : p, a); });
+        if (e == hipSuccess && launches_done == 0 && t->cl_post) {   // a driver's follow-up, decided on the device (see tsp_dev_tours::cl_post)
+            t->cl_post(t->cl_post_ctx, s, a.err);
+            t->cl_post = nullptr; t->cl_post_ran = true;
+        }
         if (e != hipSuccess) {
             // the attribute or the launch was refused (an LDS size this device does not grant): nothing ran, the tours in
             // HBM are as they were -- the caller may go on with another engine

@@ -67,8 +67,8 @@ __global__ void k_rearm(TourState *states, int B, int first_chunk) {
 // are stamped with iter (:306-309 -- the policy update in between does not read them).  result = {accepted, a1, b1, 0}.
 // list != nullptr: the handle's list of non-zero stamps is current; the two stamped edges join it unless they are in it
 // already (as entries whose stamp had been cleared).
-__global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *pos, int *stamp, int n, int a, int b, int iter,
-                                                             int tenure, int *result, int2 *list, int *list_n, int list_cap) {
+__device__ __forceinline__ void tabu_kick_body(int *order, int *pos, int *stamp, int n, int a, int b, int iter, int tenure, int *result,
+                                               int2 *list, int *list_n, int list_cap) {
     __shared__ int s_acc, s_pa, s_pb, s_a1, s_b1, s_have[2];
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -110,6 +110,35 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *po
         order[p] = w; order[q] = u;
         pos[w] = p; pos[u] = q;
     }
+}
+__global__ __launch_bounds__(kApplyThreads) void k_tabu_kick(int *order, int *pos, int *stamp, int n, int a, int b, int iter,
+                                                             int tenure, int *result, int2 *list, int *list_n, int list_cap) {
+    tabu_kick_body(order, pos, stamp, n, a, b, iter, tenure, result, list, list_n, list_cap);
+}
+
+// The tail of one tabu() iteration, queued right behind the CLUSTER launch of its alg_2opt_tabu and decided here: when that launch
+// finished the descent (done, no give-up), the incumbent is compared with the finished tour's cost (tabusearch.c:241-249; the host
+// passes the incumbent's cost), the tour is kept as the new incumbent if it is better (order -> snap), and the kick's trial runs as
+// k_tabu_kick would (:262-309).  result[4] = 1: all of that has happened (result[5]: the incumbent improved); 0: nothing was
+// touched -- the host goes the two-wait way.
+__global__ __launch_bounds__(kApplyThreads) void k_tabu_post(const TourState *state, const int *err, int *order, int *pos, int *stamp, int n,
+                                                             int a, int b, int iter, int tenure, int *result, int2 *list, int *list_n,
+                                                             int list_cap, double best_obj, int *snap) {
+    __shared__ int s_go, s_better;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const int go = state->done && !(err && *err);
+        s_go = go; s_better = go && state->obj < best_obj;
+        result[4] = go; result[5] = s_better; result[6] = 0; result[7] = 0;
+        if (!go) { result[0] = 0; result[1] = 0; result[2] = 0; result[3] = 0; }
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (s_better) {
+        for (int p = tid; p < n; p += kApplyThreads) snap[p] = order[p];
+        __syncthreads();
+    }
+    tabu_kick_body(order, pos, stamp, n, a, b, iter, tenure, result, list, list_n, list_cap);
 }
 
 // HEU_VNS's kick (src/vns.c:11-100) on tour 0: with tour[] the walk from node 0, positions p1 < p2 < p3 (host draws),
@@ -508,8 +537,8 @@ int tsp_grid_rearm(tsp_dev_tours *t, int mode) {
 
 static int kick_buffers(tsp_dev_tours *t) {
     if (!t->d_kick_result) {
-        TSP_HIP_TRY(hipMalloc(&t->d_kick_result, 4 * sizeof(int)));
-        TSP_HIP_TRY(hipHostMalloc(&t->h_kick_result, 4 * sizeof(int)));
+        TSP_HIP_TRY(hipMalloc(&t->d_kick_result, 8 * sizeof(int)));
+        TSP_HIP_TRY(hipHostMalloc(&t->h_kick_result, 8 * sizeof(int)));
     }
     return TSP_OK;
 }
@@ -585,11 +614,45 @@ int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int 
     if (!rc) rc = kick_buffers(t);
     if (rc) return rc;
     int done = 0;
-    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 2, &done);
-    if (status < 0) return status;
     hipStream_t s = t->inst->ctx->stream;
+    // The CLUSTER engine finishes the descent in one launch (almost always): the incumbent's update and the kick are queued
+    // behind that launch and decided on the device, and the iteration is ONE wait for the device.  Anything else (another
+    // engine, a second launch, a give-up, the time limit) leaves result[4] = 0 and takes the two waits below.
+    struct Post { tsp_dev_tours *t; tsp_dev_tabu *tabu; int a, b, iter, tenure; double best; } post{t, tabu, a, b, iter, tenure, *best_obj};
+    const size_t bn = (size_t)t->n;
+    if (!t->d_order_snap) TSP_HIP_TRY(hipMalloc(&t->d_order_snap, bn * sizeof(int)));
+    t->h_kick_result[4] = 0;
+    t->cl_post_ctx = &post; t->cl_post_ran = false;
+    t->cl_post = [](void *ctx, hipStream_t st, const int *d_err) {
+        Post *q = static_cast<Post *>(ctx);
+        tsp_dev_tours *tt = q->t;
+        hipLaunchKernelGGL(k_tabu_post, dim3(1), dim3(kApplyThreads), 0, st, tt->d_state, d_err, tt->d_order, tt->d_pos, q->tabu->d_stamp, tt->n,
+                           q->a, q->b, q->iter, q->tenure, tt->d_kick_result, q->tabu->list_valid ? q->tabu->d_list : nullptr, q->tabu->d_list_n,
+                           q->tabu->list_cap, q->best, tt->d_order_snap);
+        (void)hipMemcpyAsync(tt->h_kick_result, tt->d_kick_result, 8 * sizeof(int), hipMemcpyDeviceToHost, st);
+    };
+    const int status = tsp_tabu_run(t, tabu, iter, tenure, time_limit_s, 2, &done);
+    const bool post_ran = t->cl_post_ran;
+    t->cl_post = nullptr; t->cl_post_ctx = nullptr; t->cl_post_ran = false;
+    if (status < 0) return status;
     if (improved) *improved = 0;
     if (accepted) *accepted = 0;
+    if (post_ran && t->h_kick_result[4]) {   // the run's own wait has brought the result back
+        TSP_HIP_TRY(hipGetLastError());
+        const double cost = t->h_state[0].obj;
+        if (obj) *obj = cost;
+        if (t->h_kick_result[5]) {
+            *best_obj = cost;
+            if (improved) *improved = 1;
+            t->h_obj_snap.assign(1, cost);
+        }
+        if (t->h_kick_result[0] && tabu->list_valid) {
+            tabu->list_ub += 2;
+            if (tabu->list_ub > tabu->list_cap) tabu->list_valid = false;
+        }
+        if (accepted) *accepted = t->h_kick_result[0];
+        return status;
+    }
     if (status != TSP_OK || !done) {   // time limit: the cost was recomputed by the run; no kick (tabusearch.c:255-258)
         TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
         TSP_HIP_TRY(hipStreamSynchronize(s));
