@@ -209,7 +209,8 @@ int tsp_dev_tours_two_opt_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, i
  * node or one of (a,a1) (b,b1) (a,b) (a1,b1) is in the tabu list (check_tenure with its lazy clears, in that order); else
  * the 2-exchange is carried out and (a,a1), (b,b1) are stamped with iter.  *accepted = 1 / 0. */
 int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, int iter, int tenure, int *accepted);
-/* One iteration of tabu() (src/tabusearch.c:238-309) in two waits for the device: alg_2opt_tabu on resident tour 0; if its
+/* One iteration of tabu() (src/tabusearch.c:238-309) in one wait for the device (two when the descent does not finish in the
+ * CLUSTER engine's first launch): alg_2opt_tabu on resident tour 0; if its
  * cost is below *best_obj the tour becomes the incumbent (as tsp_dev_tours_snapshot; *best_obj updated, *improved = 1,
  * :241-249); then ONE trial of the kick with the host-drawn a, b (as tsp_dev_tours_tabu_kick; *accepted) -- further
  * trials, if that one is rejected, go through tsp_dev_tours_tabu_kick.  Returns the run's status; with a time limit hit
