@@ -53,7 +53,7 @@ constexpr int kApplyThreads = 1024;
 // instance handle (tsp_dev_inst_create) into this table; nothing on a call path calls getenv. ------------------------------
 #define TSP_SWITCH_LIST(X)                                                                                                  \
     X(ENGINE) X(CLUSTER_BLOCKS) X(CLUSTER_MIN_ROWS) X(CLUSTER_MAX_ROWS) X(CLUSTER_HIT_CAP) X(CLUSTER_SPIN_LIMIT)            \
-    X(CLUSTER_SPIN_MS) X(CLUSTER_COPIES) X(CLUSTER_XCD_LOCAL) X(CLUSTER_ALLOW_OVERSUB) X(CLUSTER_DEBUG) X(CLUSTER_PROBE) X(CLUSTER_FIRST_SORTED) X(TABU_DENSE)     \
+    X(CLUSTER_SPIN_MS) X(CLUSTER_COPIES) X(CLUSTER_TILE_ROWS) X(CLUSTER_XCD_LOCAL) X(CLUSTER_ALLOW_OVERSUB) X(CLUSTER_DEBUG) X(CLUSTER_PROBE) X(CLUSTER_FIRST_SORTED) X(TABU_DENSE)     \
     X(LDS_PROBE) X(LDS_PROBE2) X(LDS_MIN_ROWS) X(LDS_EDGE_CACHE) X(NO_ICOORD) X(NO_FILTER) X(NO_PRUNE) X(SORTED_MIN_N)      \
     X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
     X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \

@@ -1743,10 +1743,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     a.margin = inst->filter_margin; a.prune = inst->prune_margin; a.sum_margin = inst->sum_margin;
     // FIRST chunk geometry: the chunk adapts to the distance between hits (see the kernel's control block); the largest
     // keeps every workgroup busy for a few tiles
-    {   // rows that cost (almost) nothing more than one: every workgroup at most one tile of at most two rows (measured:
-        // rand10000 on 256 workgroups is best at 24-36 rows, 16 random tours of rand5000 on 16 workgroups each at 1-2)
+    {   // rows that cost (almost) nothing more than one: every workgroup at most one tile of at most four rows -- one trip of
+        // the tile's row loop (measured, rand10000 on 256 workgroups: 24 / 36 / 48 / 52 rows = 16.8 / 16.4 / 16.3 / 17.0 ms per
+        // descent; round 2, when a tile ended with a workgroup reduction, had its optimum at two rows per tile)
         const int nb = (n + kClThreads - 1) / kClThreads;
-        a.rmin = std::max(1, std::min(2048, TSP_SW(inst, CLUSTER_MIN_ROWS, std::max(1, 2 * (C / nb)))));
+        a.rmin = std::max(1, std::min(2048, TSP_SW(inst, CLUSTER_MIN_ROWS, std::max(1, TSP_SW(inst, CLUSTER_TILE_ROWS, 4) * (C / nb)))));
         a.rcap = std::max(a.rmin, TSP_SW(inst, CLUSTER_HIT_CAP, 4) * a.rmin);   // largest chunk right after a hit
         a.rbs = C / nb;
     }
