@@ -1012,7 +1012,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     // full record, the adjacency / cursor / key tests and the fp64 tiers are for the survivors only.  A sweep that
                     // finds nothing (every first-improvement descent ends with one, HEU_VNS runs five or six per round) is this loop.
                     const float cxf = act ? (float)rj.x : 0.f, cyf = act ? (float)rj.y : 0.f, cdf = act ? (float)rj.ds : 0.f;
-                    constexpr int RQ = 4;   // rows per trip: four LDS reads in flight, one vote
+#ifndef TSP_CL_RQ
+#define TSP_CL_RQ 4
+#endif
+                    constexpr int RQ = TSP_CL_RQ;   // rows per trip: their LDS reads in flight together, one vote
                     for (int r0 = 0; r0 < nr; r0 += RQ) {
                         float4 rf[RQ];
                         bool need[RQ];

@@ -707,8 +707,9 @@ int tsp_lds_run(tsp_dev_tours *t, int mode, double time_limit_s, int *all_done) 
     if (!t || !tsp_lds_fits(t->inst)) return TSP_DEV_E_ARG;
     hipStream_t s = t->inst->ctx->stream;
     const double t0 = wall_s();
-    // smallest chunk ~4000 pairs (measured: att532 best at 8 rows, rand5000 at 1-2 rows)
-    const int auto_rmin = std::max(1, std::min(16, (4000 + t->n / 2) / t->n));
+    // smallest chunk ~4000 pairs, at least the four rows of one trip of the row loop (measured: att532 best at 8 rows; rand5000
+    // x 128: 1 / 2 / 4 / 8 rows = 196.7 / 193.1 / 189.7 / 196.7 ms)
+    const int auto_rmin = std::max(4, std::min(16, (4000 + t->n / 2) / t->n));
     const int rmin = std::max(1, std::min(kLdsRows, TSP_SW(t->inst, LDS_MIN_ROWS, auto_rmin)));
     const int rmax = kLdsRows;
     const int max_iters = mode == TSP_2OPT_FIRST ? 8192 : 256;
