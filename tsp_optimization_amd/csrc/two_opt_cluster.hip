@@ -1750,7 +1750,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         // the tile's row loop (measured, rand10000 on 256 workgroups: 24 / 36 / 48 / 52 rows = 16.8 / 16.4 / 16.3 / 17.0 ms per
         // descent; round 2, when a tile ended with a workgroup reduction, had its optimum at two rows per tile)
         const int nb = (n + kClThreads - 1) / kClThreads;
-        a.rmin = std::max(1, std::min(2048, TSP_SW(inst, CLUSTER_MIN_ROWS, std::max(1, TSP_SW(inst, CLUSTER_TILE_ROWS, 4) * (C / nb)))));
+        a.rmin = std::max(1, std::min(2048, TSP_SW(inst, CLUSTER_MIN_ROWS, std::max(1, TSP_SW(inst, CLUSTER_TILE_ROWS, 4) * std::max(1, C / nb)))));
         a.rcap = std::max(a.rmin, TSP_SW(inst, CLUSTER_HIT_CAP, 4) * a.rmin);   // largest chunk right after a hit
         a.rbs = C / nb;
     }
