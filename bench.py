@@ -599,7 +599,7 @@ def main():
             "frac": ops / (kms * 1e-3) / FP64_LANE_OPS_PEAK, "unit": "T lane-op/s",
             "reference_equivalent_evals_per_s": stf["evals"] / (kms * 1e-3),
             "sweep_that_finds_nothing_us_per_call": 1e6 * float(np.mean(t_nohit[2:])),
-            "note": "a chain of 2 704 dependent moves: 5.8 us per step, 3.1 of it one all-to-all exchange (DESIGN.md 4.8)"}
+            "note": "a chain of 2 704 dependent moves: 5.8 us per step, 3.1 of it one all-to-all exchange (DESIGN.md 4.8, 4.8c)"}
 
     if rank == 0:
         guarded("roofline", roofline_section)
@@ -732,10 +732,10 @@ def main():
                                "(rand5000: 40 k per individual), so more GPUs shorten the chain only by giving a tour more workgroups",
             "expected_2opt_ms_per_rank_measured_on_one_gpu": {
                 "world": [1, 2, 4, 8],
-                "config4_att532_256_starts": [2.9, 2.9, 3.1, 2.3],
-                "config5_rand5000_128_individuals": [197, 183, 157, 146],
+                "config4_att532_256_starts": [2.9, 2.9, 2.9, 2.4],
+                "config5_rand5000_128_individuals": [190, 183, 154, 145],
                 "engine": ["LDS (1 workgroup per tour)", "CLUSTER (4 per tour)", "CLUSTER (8)", "CLUSTER (16)"],
-                "source": "tools/pop_time.py, tools/shard_time.py (DESIGN.md section 5): 1.35 x on 8 GPUs for configs[4], 1.25 x for configs[3]"}}
+                "source": "tools/pop_time.py, tools/shard_time.py (DESIGN.md section 5): 1.31 x on 8 GPUs for configs[4], 1.2 x for configs[3]"}}
         out["all_checks_ok"] = bool(out.get("parity", {}).get("final_tour_matches_golden", True) and
                                     all(v for d in out["other_configs"].values() for k, v in d.items()
                                         if k.startswith(("winner_", "every_"))))
