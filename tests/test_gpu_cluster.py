@@ -260,14 +260,19 @@ def test_cluster_gives_up_and_the_descent_is_redone_on_the_grid_engine(eng, ctx,
 
 
 # ---- drivers on resident tours: the kicks of tabu() and HEU_VNS on the device --------------------------------------
-@pytest.mark.parametrize("fused", [False, True])
-def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused):
-    """fused: tsp_dev_tours_tabu_iteration (run + incumbent + first kick trial in one call) instead of the separate calls.
+@pytest.mark.parametrize("fused", [False, True, "grid"])
+def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused, monkeypatch):
+    """fused: tsp_dev_tours_tabu_iteration (run + incumbent + first kick trial in one call) instead of the separate calls --
+    on the CLUSTER engine one wait for the device (the incumbent's update and the kick are decided on the device, k_tabu_post),
+    "grid": the same call with the GRID engine forced, i.e. the two-wait path.  At the end the incumbent kept on the device is
+    the tour the host replay saw when the cost last improved.
     tabusearch.c:238-309 through the resident-tour API: alg_2opt_tabu on the device-resident tour with device-resident
     stamps, then the kick as one launch per trial (host-drawn a, b; check_tenure with its lazy clears; 2-exchange; stamps).
     After 60 iterations the tour, its cost and the whole stamp array equal a host replay with the oracle's alg_2opt_tabu."""
     xy, wt = load_instance("pr299")
     n = len(xy)
+    if fused == "grid":
+        monkeypatch.setenv("TSP_ENGINE", "1")
     inst = eng.Instance(ctx, xy, wt, 1)
     _, succ0, obj0 = O.greedy(xy, wt)
     tours = eng.Tours(inst, 1)
@@ -275,6 +280,7 @@ def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused):
     tabu = eng.Tabu(inst)
     stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
     succ = succ0.copy()
+    best_succ = None
     rng = np.random.default_rng(11)
     lo, hi = int(np.ceil(n * 0.02)), int(round(n * 0.1))
     tenure = lo
@@ -305,6 +311,8 @@ def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused):
             rc, obj = tours.two_opt_tabu(tabu, it, tenure)
         _, succ, eo, _, _, prev = O.two_opt_best(xy, wt, succ, tabu=stamps, iter_=it, tenure=tenure, want_prev=True)
         assert rc == 0 and obj == eo, it
+        if fused and improved:
+            best_succ = succ.copy()
         while True:
             if first_trial is not None:
                 a, b, acc = first_trial
@@ -340,6 +348,13 @@ def test_resident_tabu_iterations_equal_oracle(eng, ctx, fused):
     s, o, _ = tours.download()
     assert (s[0] == succ).all()
     assert (tabu.download() == stamps).all()
+    if fused:
+        assert best_succ is not None
+        tours.restore()
+        s, o, _ = tours.download()
+        assert o[0] == best and O.succ_cost(xy, wt, s[0]) == best
+        assert set(zip(range(n), s[0].tolist())) == set(zip(range(n), best_succ.tolist())) or \
+            set(zip(s[0].tolist(), range(n))) == set(zip(range(n), best_succ.tolist()))   # the same cycle (either orientation)
     tabu.close(); tours.close(); inst.close()
 
 
