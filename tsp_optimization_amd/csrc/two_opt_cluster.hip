@@ -524,16 +524,36 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
 
     // longest tour edge incident to a node of group g, for the groups g0, g0 + stride, ... (one wave per group)
     auto group_bounds = [&](int g0, int stride, int gend) {
-        for (int g = g0; g < gend; g += stride) {
-            const int v = g * 64 + lane;
-            double m = 0.0;
-            if (v < n) {
-                const int p = (int)pos[v];
-                const int su = (int)order[p + 1 == n ? 0 : p + 1], pr = (int)order[p == 0 ? n - 1 : p - 1];
-                m = fmax(cl_dist<WT, INT, CT>(coord, v, su), cl_dist<WT, INT, CT>(coord, v, pr));
+        // four groups at a time: their chains of dependent LDS reads (position, two neighbours, three coordinates) advance together
+        // (a launch of the sorted scan starts with all ng groups: 20 per wave at n = 10 000, the largest fixed item of a short launch)
+        constexpr int GU = 4;
+        for (int gb = g0; gb < gend; gb += stride * GU) {
+            int v[GU], p[GU], su[GU], pr[GU];
+            double m[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                v[u] = (gb + u * stride) * 64 + lane;
+                p[u] = (int)pos[min(v[u], n - 1)];
             }
-            m = cl_wave_max_nonneg(m);
-            if (lane == 0) gmax[g] = m;
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                su[u] = (int)order[p[u] + 1 == n ? 0 : p[u] + 1];
+                pr[u] = (int)order[p[u] == 0 ? n - 1 : p[u] - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int vc = min(v[u], n - 1);
+                m[u] = fmax(cl_dist<WT, INT, CT>(coord, vc, su[u]), cl_dist<WT, INT, CT>(coord, vc, pr[u]));
+                if (v[u] >= n) m[u] = 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int g = gb + u * stride;
+                if (g < gend) {   // wave-uniform
+                    const double mm = cl_wave_max_nonneg(m[u]);
+                    if (lane == 0) gmax[g] = mm;
+                }
+            }
         }
     };
     // first improvement on the rank-order replica: the group bounds are only read by a box-pruned step; moves made by tiles /
