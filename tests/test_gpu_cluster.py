@@ -394,3 +394,27 @@ def test_resident_vns_rounds_equal_oracle(eng, ctx):
     s, o, _ = tours.download()
     assert (s[0] == best).all() and o[0] == best_obj
     tours.close(); inst.close()
+
+
+@pytest.mark.parametrize("n,wt_name,int_coords", [(2311, "EUC_2D", True), (4099, "ATT", True), (7001, "CEIL_2D", True),
+                                                  (3001, "EUC_2D", False), (5003, "ATT", False), (9001, "EUC_2D", True)])
+def test_sorted_scan_on_256_workgroups_equals_the_grid_engine_at_mid_sizes(eng, ctx, n, wt_name, int_coords):
+    """The CLUSTER engine's best-improvement descent at sizes between the golden instances -- every metric with a distance bound,
+    integer (float replica, fp32 tiers) and fractional coordinates (double replica), groups whose last quarter is partly or wholly
+    padding -- against the GRID engine (itself pinned on the oracle at these sizes by prefixes and at 2 000 / 5 000 / 10 000 by the
+    golden descents): the same tour, cost, sweeps, evaluations, moves and reversal length; and the first-improvement descent too."""
+    rng = np.random.default_rng(n)
+    xy = rng.integers(0, 500_000, size=(n, 2)).astype(np.float64)
+    if not int_coords:
+        xy = xy + rng.integers(0, 8, size=(n, 2)) * 0.125
+    wt = getattr(O, wt_name)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    succ0, obj0, _ = inst.construct(eng.GREEDY, np.array([3], dtype=np.int32))
+    for mode in (eng.BEST, eng.FIRST):
+        rc1, s1, o1, st1 = inst.two_opt(succ0[0], obj0[0], mode=mode, engine=eng.ENGINE_GRID)
+        rc3, s3, o3, st3 = inst.two_opt(succ0[0], obj0[0], mode=mode, engine=eng.ENGINE_CLUSTER)
+        assert rc1 == 0 and rc3 == 0
+        assert o1 == o3 and (s1 == s3).all() and O.is_tour(s3)
+        assert (st1["sweeps"], st1["evals"], st1["moves"], st1["reversed"]) == (st3["sweeps"], st3["evals"], st3["moves"], st3["reversed"])
+        assert O.succ_cost(xy, wt, s3) == o3
+    inst.close()
