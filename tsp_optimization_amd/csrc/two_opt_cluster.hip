@@ -770,13 +770,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 // The survivors, P group pairs at a time.  Work is dealt in three grains, because a step costs the time of its
                 // slowest wave and the pairs that reach the expensive tiers are concentrated in a few group pairs (a group
                 // against itself or its neighbours):
-                //  (1) stage: the records of both groups of every pair are derived once, one record per thread and round
-                //      (slot 2 pe = the row group, 2 pe + 1 = the column group).  A row-side thread also culls its row -- a
-                //      row that cannot reach the column group's box is dropped -- and the live rows go into one list;
-                //  (2) live rows, four at a time per wave and turn (the 64 rows of a heavy pair end up on all waves): tier 0
-                //      against the 64 columns; the pairs that survive it are queued per wave;
+                //  (1) stage: one wave per pair derives the records of both groups (lane = slot; slot block 2 pe = the row group,
+                //      2 pe + 1 = the column group), takes the box and the longest successor edge of each QUARTER of the column
+                //      group from them, and tests every row against the four quarters: a (row, quarter) pair that can hold a
+                //      candidate becomes a unit of the list;
+                //  (2) units, one per 16 lanes, two trips per wave and turn with their LDS reads issued together: tier 0 against the
+                //      quarter's 16 columns; the pairs that survive it are queued per wave;
                 //  (3) queued pairs, 64 at a time (one per lane): tiers 1 and 2 run on full waves, not on the few lanes of
-                //      a row that happen to need them.
+                //      a unit that happen to need them.
                 for (int e0 = 0; e0 < kept; e0 += P) {
                     const int ne = min(P, kept - e0);
                     if (wave == 0) w_st += ne * 128;
