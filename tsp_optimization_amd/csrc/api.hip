@@ -543,11 +543,15 @@ int tsp_dev_tours_two_opt(tsp_dev_tours *t, int mode, int engine, double time_li
     int rc = tsp_grid_rearm(t, mode);
     if (rc) return rc;
     int done = 0;
+    t->h_state_fresh = false;
     const int status = tsp_dev_tours_run_engine(t, mode, engine, -1, time_limit_s, &done);
     if (status < 0) return status;
-    hipStream_t s = t->inst->ctx->stream;
-    TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(tsp::TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
+    if (!t->h_state_fresh) {   // (the CLUSTER engine's last poll has brought the control blocks back already)
+        hipStream_t s = t->inst->ctx->stream;
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(tsp::TourState) * (size_t)t->B, hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+    }
+    t->h_state_fresh = false;
     if (obj) for (int b = 0; b < t->B; ++b) obj[b] = t->h_state[b].obj;
     return status;
 }

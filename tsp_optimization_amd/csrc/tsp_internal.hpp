@@ -185,6 +185,7 @@ struct tsp_dev_tours {
     void (*cl_post)(void *ctx, hipStream_t s, const int *d_err) = nullptr;
     void *cl_post_ctx = nullptr;
     bool cl_post_ran = false;
+    bool h_state_fresh = false;   // h_state holds what d_state holds (set by a CLUSTER run's last poll, cleared by whatever queues work after it)
     int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)
     // reset point (device copies of the uploaded tours)

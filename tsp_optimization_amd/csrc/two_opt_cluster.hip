@@ -1860,5 +1860,6 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
     bool unfinished = status == TSP_TIME_LIMIT_EXCEEDED;
     for (int b = 0; b < B; ++b) unfinished = unfinished || !t->h_state[b].done;
     const int rc = tsp_grid_after_external_run(t, mode, unfinished, /*pos_written=*/true);
+    t->h_state_fresh = rc == 0 && !(unfinished && mode == TSP_2OPT_BEST);   // (a cut-short best-improvement run has its cost recomputed after the poll)
     return rc ? rc : status;
 }
