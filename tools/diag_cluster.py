@@ -55,4 +55,10 @@ for mode, nm in [(E.FIRST, 'FIRST'), (E.BEST, 'BEST')]:
         nb = int(used.sum())
         print('  inside the scan (thread 0, mean over workgroups): stage+culling %.2f  (-) %.2f  rows+queues %.2f us/step (the rest: final barrier); live rows per workgroup and step %.1f'
               % (cnt[0] / 100.0 / steps / nb, cnt[1] / 100.0 / steps / nb, cnt[2] / 100.0 / steps / nb, cnt[3] / steps / nb))
+        b0s = (C.c_ulonglong * 8)()
+        L.tsp_dev_debug_cluster_b0.argtypes = [C.POINTER(C.c_ulonglong)]
+        L.tsp_dev_debug_cluster_b0(b0s)
+        ns = max(1, b0s[0])
+        print('  the bound a sweep starts from: mean -b0 %.0f against mean -delta of the winner %.0f; b0 == delta in %.1f %% of the sweeps, within a factor 1.25 in %.1f %%, 2 in %.1f %%'
+              % (b0s[1] / ns, b0s[2] / ns, 100.0 * b0s[3] / ns, 100.0 * b0s[5] / ns, 100.0 * b0s[4] / ns))
         print('  wave 0: tier-1/2 passes per step %.2f with %.1f pairs each' % (cnt[4] / steps / nb, cnt[5] / max(1, cnt[4])))

@@ -59,6 +59,7 @@ using gi32c = __attribute__((address_space(1))) int;
 #ifdef TSP_STAMPS
 __device__ unsigned long long g_cl_prof[256][8];
 __device__ unsigned long long g_cl_wstat[256][4];   // per workgroup of tour 0: lane pairs, tier-1 pairs, delta expressions, staged records
+__device__ unsigned long long g_cl_b0[8];   // sweeps with a winner, sum of -b0, sum of -delta of the winner, sweeps with b0 == delta, with b0 >= delta / 2, >= delta / 1.25
 __device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: units, live rows, row quads, tier-1 blocks, tier-2 pairs, survivors
 #define CL_T(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
 #else
@@ -288,7 +289,7 @@ struct ClCand {
 // exactly those nodes and of a = the winner's first node.  A candidate (u, v) of another workgroup with neither node among them
 // keeps succ u, succ v, its adjacency and therefore its delta: the next sweep's minimum is at most that.  Every workgroup holds
 // all C candidates after an exchange and computes the same value.  One wave; pos[] as it stands when the winner's positions are read.
-__device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *pos, int n) {
+__device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *pos, int n, bool inside_ok) {
     double b0 = 0.0;
     if (cd.key != kNoKey && cd.d < 0.0) {
         const int wi = (int)(cd.ipair >> 16), wj = (int)(cd.ipair & 0xffffu);
@@ -302,7 +303,11 @@ __device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *p
                 if (du < 0) du += n;
                 if (dv < 0) dv += n;
                 const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
-                if (untouched && cd.c_d[q] < b0) b0 = cd.c_d[q];
+                // both nodes strictly inside the reversed positions (pa+1 .. pb-1): their successor edges are reversed with the
+                // segment, not removed, and the same exchange of those two edges is the pair of the two old successors on the new
+                // tour -- the same four lengths, the same delta when the terms are integers (no tabu list: its four stamps differ)
+                const bool inside = inside_ok && du <= L - 2 && dv <= L - 2;
+                if ((untouched || inside) && cd.c_d[q] < b0) b0 = cd.c_d[q];
             }
         }
     }
@@ -1153,6 +1158,18 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             bool okx = true;
             if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
+#ifdef TSP_STAMPS
+            if constexpr (SORTED && BEST) {
+                if (lane == 0 && c == 0 && tour == 0 && cd.key != kNoKey) {   // how good the bound this sweep started from was
+                    atomicAdd(&g_cl_b0[0], 1ull);
+                    atomicAdd(&g_cl_b0[1], (unsigned long long)(-b0));
+                    atomicAdd(&g_cl_b0[2], (unsigned long long)(-cd.d));
+                    if (b0 == cd.d) atomicAdd(&g_cl_b0[3], 1ull);
+                    if (-b0 * 2.0 >= -cd.d) atomicAdd(&g_cl_b0[4], 1ull);
+                    if (-b0 * 1.25 >= -cd.d) atomicAdd(&g_cl_b0[5], 1ull);
+                }
+            }
+#endif
             xcd = cd;
         } else if (!probe_hit && view.L != 0) {
             swaps(view, tid - 64, kClThreads - 64);   // the pending reversal, while wave 0 exchanges
@@ -1261,7 +1278,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             }
             if constexpr (SORTED && BEST) {
                 if (a.use_b0 && wave == 0 && C > 1) {   // the bound the next sweep starts from (the exchanging wave holds the candidates)
-                    const double nb0 = cl_next_bound(xcd, pos, n);
+                    const double nb0 = cl_next_bound(xcd, pos, n, INT && !TABU);
                     if (lane == 0) *s_b0 = nb0;
                 }
             }
@@ -1541,6 +1558,12 @@ extern "C" int tsp_dev_debug_cluster_wstat(unsigned long long *out /* 256 x 4 */
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_wstat), sizeof(unsigned long long) * 256 * 4) != hipSuccess) return -1;
     static unsigned long long z[256 * 4];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_wstat), z, sizeof z);
+    return 0;
+}
+extern "C" int tsp_dev_debug_cluster_b0(unsigned long long *out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(tsp::g_cl_b0), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_b0), z, sizeof z);
     return 0;
 }
 extern "C" int tsp_dev_debug_cluster_counts(unsigned long long *out8) {
