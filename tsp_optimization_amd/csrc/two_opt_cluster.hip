@@ -289,7 +289,7 @@ struct ClCand {
 // exactly those nodes and of a = the winner's first node.  A candidate (u, v) of another workgroup with neither node among them
 // keeps succ u, succ v, its adjacency and therefore its delta: the next sweep's minimum is at most that.  Every workgroup holds
 // all C candidates after an exchange and computes the same value.  One wave; pos[] as it stands when the winner's positions are read.
-__device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *pos, int n, bool inside_ok) {
+__device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *pos, int n, bool inside_ok, unsigned (&mem_ip)[4], double (&mem_d)[4]) {
     double b0 = 0.0;
     if (cd.key != kNoKey && cd.d < 0.0) {
         const int wi = (int)(cd.ipair >> 16), wj = (int)(cd.ipair & 0xffffu);
@@ -297,18 +297,29 @@ __device__ __forceinline__ double cl_next_bound(const ClCand &cd, const idx_t *p
         int L = pb - pa; if (L < 0) L += n;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (cd.c_d[q] < 0.0) {
-                const int ui = (int)(cd.c_ip[q] >> 16), uj = (int)(cd.c_ip[q] & 0xffffu);
-                int du = (int)pos[ui] - pa - 1, dv = (int)pos[uj] - pa - 1;
-                if (du < 0) du += n;
-                if (dv < 0) dv += n;
-                const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
-                // both nodes strictly inside the reversed positions (pa+1 .. pb-1): their successor edges are reversed with the
-                // segment, not removed, and the same exchange of those two edges is the pair of the two old successors on the new
-                // tour -- the same four lengths, the same delta when the terms are integers (no tabu list: its four stamps differ)
-                const bool inside = inside_ok && du <= L - 2 && dv <= L - 2;
-                if ((untouched || inside) && cd.c_d[q] < b0) b0 = cd.c_d[q];
+            // the candidate workgroup 64 q + lane has just sent, and the best one it sent in earlier sweeps that no move has touched
+            // since (its own new candidate is at least as good -- until that one is the move, or touched by it)
+            double keep_d = 0.0;
+            unsigned keep_ip = 0u;
+#pragma unroll
+            for (int src = 0; src < 2; ++src) {
+                const double d = src ? mem_d[q] : cd.c_d[q];
+                const unsigned ip = src ? mem_ip[q] : cd.c_ip[q];
+                if (d < 0.0) {
+                    const int ui = (int)(ip >> 16), uj = (int)(ip & 0xffffu);
+                    int du = (int)pos[ui] - pa - 1, dv = (int)pos[uj] - pa - 1;
+                    if (du < 0) du += n;
+                    if (dv < 0) dv += n;
+                    const bool untouched = ui != wi && uj != wi && du >= L && dv >= L;
+                    // both nodes strictly inside the reversed positions (pa+1 .. pb-1): their successor edges are reversed with the
+                    // segment, not removed, and the same exchange of those two edges is the pair of the two old successors on the new
+                    // tour -- the same four lengths, the same delta when the terms are integers (no tabu list: its four stamps differ)
+                    const bool inside = inside_ok && du <= L - 2 && dv <= L - 2;
+                    if ((untouched || inside) && d < b0) b0 = d;
+                    if (untouched && d < keep_d) { keep_d = d; keep_ip = ip; }
+                }
             }
+            mem_d[q] = keep_d; mem_ip[q] = keep_ip;
         }
     }
     return from_ordered_bits(wave_min_u64(ordered_bits(b0)));
@@ -631,6 +642,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         }
     }
     double b0 = 0.0;      // BEST, sorted scan: bound the sweep starts from (<= 0; see cl_next_bound)
+    unsigned b0_mem_ip[4] = {0u, 0u, 0u, 0u};   // (first wave: the candidates it remembers from earlier sweeps, four workgroups per lane)
+    double b0_mem_d[4] = {0.0, 0.0, 0.0, 0.0};
     // Deferred moves.  The swaps of a move that an EXCHANGE step decided are not carried out at once: the next step scans the tour
     // through the closed form of the pending reversal (ClView), and the swaps are done by waves 1 .. 7 while wave 0 runs that
     // step's exchange -- time they would spend waiting for it.  (Not with a tabu list: those waves work on the list then.  Not for
@@ -1278,7 +1291,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             }
             if constexpr (SORTED && BEST) {
                 if (a.use_b0 && wave == 0 && C > 1) {   // the bound the next sweep starts from (the exchanging wave holds the candidates)
-                    const double nb0 = cl_next_bound(xcd, pos, n, INT && !TABU);
+                    if (a.dbg & 16) { for (int q = 0; q < 4; ++q) b0_mem_d[q] = 0.0; }   // diagnostics: no memory of earlier sweeps
+                    const double nb0 = cl_next_bound(xcd, pos, n, (INT && !TABU) && !(a.dbg & 32), b0_mem_ip, b0_mem_d);
                     if (lane == 0) *s_b0 = nb0;
                 }
             }
