@@ -610,7 +610,7 @@ def main():
             out["value_definition"] = ("lane_pairs: pairs for which a lane executed a lower bound of delta or delta itself, per second, "
                                        "timed region, whole job")
             out["value_note"] = ("value counts the pairs that reach a lane's tier 0: better pruning LOWERS it (round 2: 1.45e11 in 16.2 ms per descent; "
-                                 "round 3's quarter units send 62 % fewer pairs there: 6.7e10 in 12.4 ms, the same decisions).  Compare ms_per_step, "
+                                 "round 3's quarter units send 62 % fewer pairs there: 6.4e10 in 12.2 ms, the same decisions).  Compare ms_per_step, "
                                  "time_to_local_optimum and reference_equivalent_pairs_per_s across rounds, not value")
             out["delta_evals_per_s_exhaustive"] = ex.get("exact_delta_per_s")
             out["reference_equivalent_pairs_per_s"] = out["evals"]["reference_equivalent_pairs_per_s"]
