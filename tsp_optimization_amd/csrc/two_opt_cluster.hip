@@ -929,8 +929,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             if (tid == 0) { prof[6] += 1; prof[7] += cnt; }
 #endif
                         };
-                        // The units, 16 per wave and turn (one per 16 lanes and trip, four trips whose LDS reads are issued together);
-                        // turns dealt to the waves in turn
+                        // The units, one per 16 lanes and trip, TR trips per wave and turn with their LDS reads issued together (2 measured
+                        // best: 3 / 4 / 6 / 8 trips cost +0.5 / +1.5 / +2 / +5 % of a descent), turns dealt to the waves in turn
 #ifndef TSP_CL_TR
 #define TSP_CL_TR 2
 #endif
