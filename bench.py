@@ -245,11 +245,14 @@ def launch_ranks(argv, n_ranks):
     limit = float(os.environ.get("TSP_BENCH_LAUNCH_TIMEOUT", "3000"))
     t0 = time.time()
     codes = [None] * n_ranks
+    first_failure = None
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
                 codes[r] = p.poll()
         failed = any(c not in (None, 0) for c in codes)
+        if failed and first_failure is None:
+            first_failure = next(c for c in codes if c not in (None, 0))   # the rank that failed by itself, not the ones ended below
         if failed or time.time() - t0 > limit:
             # a rank died (or the job hangs): the others would wait in a collective for ever -- end exactly the processes
             # this parent started (by PID), give them a moment, then kill
@@ -275,7 +278,7 @@ def launch_ranks(argv, n_ranks):
             json_line = ln
         else:
             sys.stderr.write("[rank 0] %s\n" % ln)
-    rc = next((c for c in codes if c), 0)
+    rc = first_failure if first_failure is not None else next((c for c in codes if c), 0)
     if json_line is None and rc == 0:
         rc = 1
     sys.stderr.flush()

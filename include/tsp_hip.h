@@ -232,6 +232,9 @@ int tsp_dev_tours_restore(tsp_dev_tours *t);
  * launches in *mean_ms and the reference-equivalent evaluations per step in *evals_per_launch.
  * Roofline measurement. */
 int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t *evals_per_launch);
+/* Diagnostics: the kernels one GRID-engine step of `mode` launches for this handle, as text (bench.py names the kernel its
+ * roofline describes from this; tests check that a switch selected the path they mean to test). */
+int tsp_dev_tours_describe(tsp_dev_tours *t, int mode, char *buf, int cap);
 /* min over tours of (cost, tour index) packed as (int64(cost) << 24 | index); the value the
  * multi-start all-reduce(min) combines across ranks.  true_cost != 0 recomputes the cost from
  * the tour (GRASP's reported value carries an offset).  Written to *packed. */
@@ -261,12 +264,19 @@ int tsp_dev_comm_info(const tsp_dev_comm *comm, int *rank, int *world, int *rccl
 int tsp_dev_multistart_pack(double cost, int start_id, int64_t *packed);
 /* all-reduce(min) of one int64 per rank over RCCL; every rank receives the minimum. */
 int tsp_dev_multistart_allreduce(tsp_dev_comm *comm, int64_t packed_local, int64_t *packed_best);
+/* all-reduce(min) of one double per rank: the first of the TWO reductions that carry costs the packed word cannot (--fcost,
+ * src/utility.c:285; `< bestobj` on doubles, src/heuristics.c:534) -- min of the cost, then tsp_dev_multistart_allreduce of the
+ * start id among the ranks whose cost equals that minimum (ties -> lowest start, the strict `<` in stream order). */
+int tsp_dev_multistart_allreduce_f64(tsp_dev_comm *comm, double cost_local, double *cost_best);
+/* Every collective of this group waits at most TSP_COMM_TIMEOUT_S (300) seconds for its peers; after that the communicator is
+ * aborted and the call returns TSP_DEV_E_COMM (RCCL itself would wait for ever for a rank that died before the collective). */
 /* broadcast of n ints (a successor list, `succ_stride` ints apart: 2 for &inst->solution.edges[0].j) from rank `root`. */
 int tsp_dev_multistart_bcast_tour(tsp_dev_comm *comm, int root, int *succ, int succ_stride, int n);
 /* The same two collectives for all ndev communicators of ONE process (ncclGroupStart / ncclGroupEnd around them).
  * packed_local[k] / packed_best[k] belong to rank k; the tour travels from rank `root`'s device to every device and is
  * read back from `read_back_rank`'s (so that a caller can check what a non-root rank received). */
 int tsp_dev_multistart_allreduce_group(tsp_dev_comm *const *comms, int ndev, const int64_t *packed_local, int64_t *packed_best);
+int tsp_dev_multistart_allreduce_f64_group(tsp_dev_comm *const *comms, int ndev, const double *cost_local, double *cost_best);
 int tsp_dev_multistart_bcast_tour_group(tsp_dev_comm *const *comms, int ndev, int root, const int *succ_root, int succ_stride,
                                         int n, int read_back_rank, int *succ_out);
 

@@ -55,6 +55,7 @@ def lib():
         L.orc_greedy.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, ip, dp]
         L.orc_grasp.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_int, dp, ip, dp]
         L.orc_greedy_iter.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
+        L.orc_grasp_iter_prefix.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_longlong, ip, dp, C.POINTER(C.c_longlong)]
         L.orc_extramileage.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp]
         L.orc_two_opt_first.argtypes = [dp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_double, C.c_int,
                                         C.POINTER(Stats), C.POINTER(Move), C.c_longlong]
@@ -146,6 +147,16 @@ def grasp(xy, wtype, start=0, integer_cost=1, urand=None):
         up = _d(urand)
     st = lib().orc_grasp(_d(xy), n, wtype, integer_cost, start, up, _i(succ), C.byref(obj))
     return st, succ, obj.value
+
+
+def grasp_iter_prefix(xy, wtype, starts, integer_cost=1):
+    """HEU_Grasp_iter for exactly `starts` starts of the libc stream (seed it first) -> (succ, obj, index of the best start)."""
+    xy = _xy(xy)
+    n = len(xy)
+    succ = np.zeros(n, dtype=np.int32)
+    obj, k = C.c_double(0), C.c_longlong(-1)
+    lib().orc_grasp_iter_prefix(_d(xy), n, wtype, integer_cost, C.c_longlong(starts), _i(succ), C.byref(obj), C.byref(k))
+    return succ, obj.value, k.value
 
 
 def greedy_iter(xy, wtype, integer_cost=1):

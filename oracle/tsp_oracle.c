@@ -159,6 +159,25 @@ int orc_grasp(const double *xy, int n, int wtype, int integer_cost, int start, c
     return ORC_OK;
 }
 
+/* src/heuristics.c:510-544 for exactly `starts` starts instead of a wall-clock bound (which no test can reproduce): start
+ * node from the libc stream (:519), grasp() drawing its n values from the same stream (:127), the first strictly better
+ * start kept (:534-539).  *best_start = its index in the stream.  The caller seeds the stream. */
+int orc_grasp_iter_prefix(const double *xy, int n, int wtype, int integer_cost, long long starts, int *succ, double *obj,
+                          long long *best_start) {
+    int *trial = malloc(sizeof(int) * (size_t)n);
+    double best = DBL_MAX;
+    *best_start = -1;
+    for (long long k = 0; k < starts; k++) {
+        const int node = (int)(orc_urand() * (n - 1));
+        double c;
+        orc_grasp(xy, n, wtype, integer_cost, node, NULL, trial, &c);
+        if (c < best) { best = c; *best_start = k; memcpy(succ, trial, sizeof(int) * (size_t)n); }
+    }
+    *obj = best;
+    free(trial);
+    return ORC_OK;
+}
+
 /* src/heuristics.c:168-205 */
 int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj) {
     int *trial = malloc(sizeof(int) * (size_t)n);

@@ -63,6 +63,9 @@ int orc_grasp(const double *xy, int n, int wtype, int integer_cost, int start, c
               int *succ, double *obj);
 
 /* src/heuristics.c:168-205 (all n starting nodes, keep the best) */
+/* HEU_Grasp_iter (src/heuristics.c:510-544) for exactly `starts` starts of the libc stream */
+int orc_grasp_iter_prefix(const double *xy, int n, int wtype, int integer_cost, long long starts, int *succ, double *obj,
+                          long long *best_start);
 int orc_greedy_iter(const double *xy, int n, int wtype, int integer_cost, int *succ, double *obj);
 
 /* src/heuristics.c:208-314 (farthest pair + cheapest insertion) */

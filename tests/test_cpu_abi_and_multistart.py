@@ -46,6 +46,11 @@ def test_libtsp_host_exports_the_reference_entry_points(built):
               "HEU_2opt_greedy_iter", "reverse_path", "copy_instance", "rand_choice", "x_udir_pos",
               "get_elapsed_time", "free_instance", "TSP_heuc", "parse_comand_line", "parse_instance",
               "export_tour", "fitness_batch", "HEU_2opt_grasp_multistart", "tsp_host_multistart_gpus", "tsp_host_multistart_shard",
+              "HEU_2opt_population_multistart", "tsp_host_population_gpus", "tsp_host_population_shard",
+              "tsp_host_multistart_epilogue", "tsp_host_multistart_last_error", "tsp_host_set_collectives",
+              "tsp_host_rccl_id_file_state", "tsp_host_last_grasp_iter_starts", "tsp_host_genetic_gpus", "tsp_host_genetic_ex",
+              "tsp_host_vns", "tsp_host_tabu", "HEU_VNS", "HEU_Tabu_step", "HEU_Tabu_lin", "HEU_Tabu_rand", "HEU_Genetic",
+              "HEU_extramileage", "HEU_2opt_extramileage", "kick",
               "tsp_host_last_stats", "tsp_host_shutdown"]:
         assert hasattr(L, n), n
 
@@ -159,8 +164,30 @@ def refine(ids):
     calls.append(list(ids))
     return [table[k]["opt_true"] for k in ids], np.stack([np.full(n, k, dtype=np.int32) for k in ids])
 out = M.run_sharded(refine, len(table), n, rank, world)       # the launcher bench.py drives on the GPUs
-print(json.dumps({"rank": rank, "n_mine": out["local_starts"], "cost": out["cost"], "start": out["start"],
-                  "tour_ok": bool((out["tour"] == out["start"]).all()), "ids_ok": calls == [M.shard_starts(len(table), rank, world)]}))
+res = {"rank": rank, "n_mine": out["local_starts"], "cost": out["cost"], "start": out["start"],
+       "tour_ok": bool((out["tour"] == out["start"]).all()), "ids_ok": calls == [M.shard_starts(len(table), rank, world)]}
+# --fcost: the same launcher with costs the packed word cannot carry -> two reductions (min of the double, min of the start
+# among its holders); table = the oracle's 256 starts of att532 with integer_cost = 0
+ftab = json.load(open(os.path.join(sys.argv[1], "tests/golden/oracle_vectors_fcost.json")))["starts"]
+fref = lambda ids: ([float.fromhex(ftab[k]["cost_hex"]) for k in ids], np.stack([np.full(n, k, dtype=np.int32) for k in ids]))
+fo = M.run_sharded(fref, len(ftab), n, rank, world, integer_costs=False)
+res["fcost"] = [fo["cost"].hex(), fo["start"], bool((fo["tour"] == fo["start"]).all())]
+# ties between the ranks: the lowest start wins whatever rank holds it
+tie = M.run_sharded(lambda ids: ([2.5 if k in (5, 2) else 9.75 for k in ids], np.stack([np.full(n, k, dtype=np.int32) for k in ids])),
+                    8, n, rank, world, integer_costs=False)
+res["fcost_tie"] = [tie["cost"], tie["start"], bool((tie["tour"] == 2).all())]
+# a rank whose refine raises: the failure travels through the reduction, EVERY rank raises, none waits in a collective
+def bad(ids):
+    if rank == 1:
+        raise RuntimeError("shard of rank 1 broke")
+    return fref(ids)
+for name, ic in (("fail_int", True), ("fail_f", False)):
+    try:
+        M.run_sharded(bad, len(ftab), n, rank, world, integer_costs=ic)
+        res[name] = "returned"
+    except Exception as e:
+        res[name] = type(e).__name__
+print(json.dumps(res))
 dist.destroy_process_group()
 '''
 
@@ -182,6 +209,12 @@ def test_multistart_allreduce_world2_gloo(tmp_path):
     for o in outs:
         assert (o["cost"], o["start"]) == (exp["best_true"], exp["best_start"])   # 28998 at start 122
         assert o["n_mine"] == 128 and o["tour_ok"] and o["ids_ok"]                # every rank holds the winner's tour
+    fbest = golden("oracle_vectors_fcost.json")["best"]
+    for r, o in enumerate(outs):
+        assert o["fcost"] == [fbest["cost_hex"], fbest["k"], True]                # bit-identical double, start 67
+        assert o["fcost_tie"] == [2.5, 2, True]
+        assert o["fail_int"] == ("RuntimeError" if r == 1 else "UnpackableCost")  # both raised; nobody hung
+        assert o["fail_f"] == "RuntimeError"
 
 
 def test_bench_self_launcher_world2_gloo():

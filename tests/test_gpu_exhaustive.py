@@ -1,0 +1,118 @@
+"""GPU: the exhaustive best-improvement sweep in tour-position order (csrc/two_opt_exh.hpp: k_move_pos + k_exh) -- what
+TSP_NO_FILTER=1 runs on the integer-coordinate metrics and what bench.py times: every delta expression of
+src/tabusearch.c:127-157 executed, one new distance per pair.  It must take the reference's decisions exactly: whole descents
+against the oracle (tour, cost, sweeps, evaluations, moves), at the sizes where its strips, halos and segments change shape,
+on all three integer-root metrics, with ties, duplicate points, batches -- and the full 1 428-sweep descent of rand10000."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from helpers import golden, load_instance, rand_instance, random_tour
+
+pytestmark = pytest.mark.gpu
+BIG = golden("oracle_vectors_big.json")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from tsp_optimization_amd import engine as E
+    assert E.device_count() >= 1
+    return E
+
+
+@pytest.fixture(scope="module")
+def ctx(eng):
+    c = eng.Context(0)
+    yield c
+    c.close()
+
+
+def _descent(eng, ctx, monkeypatch, xy, wt, succ0, env=None, expect_exh=True):
+    monkeypatch.setenv("TSP_NO_FILTER", "1")
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    t = eng.Tours(inst, 1)
+    assert ("k_exh" in t.describe(eng.BEST)) == expect_exh, t.describe(eng.BEST)
+    t.upload(succ0, 0.0)
+    rc, done = t.run_engine(eng.BEST, engine=eng.ENGINE_GRID)
+    s, o, st = t.download()
+    t.close()
+    inst.close()
+    assert rc == 0 and done
+    return s[0], o[0], st[0]
+
+
+def _check(eng, ctx, monkeypatch, xy, wt, succ0, env=None):
+    s, o, st = _descent(eng, ctx, monkeypatch, xy, wt, succ0, env)
+    _, es, eo, est, _, _ = O.two_opt_best(xy, wt, succ0)
+    assert (s == es).all() and o == eo, (len(xy), env)
+    assert (st["sweeps"], st["evals"], st["moves"], st["reversed"]) == (est["sweeps"], est["evals"], est["moves"], est["reversed"])
+
+
+@pytest.mark.parametrize("n", [5, 6, 7, 8, 52, 63, 64, 65, 126, 127, 128, 129, 254, 255, 256, 300, 511, 777])
+def test_exhaustive_descents_equal_the_oracle_at_strip_boundaries(eng, ctx, monkeypatch, n):
+    """A strip is 64 RJ - 1 pair-columns wide (127 with the default RJ = 2): sizes around one, two, four strips, and tiny ones."""
+    xy = rand_instance(n, seed=100 + n, hi=5000)
+    rng = np.random.default_rng(n)
+    _check(eng, ctx, monkeypatch, xy, O.EUC_2D, random_tour(n, rng))
+
+
+@pytest.mark.parametrize("rj,waves", [("1", "1"), ("1", "8"), ("2", "2"), ("4", "1"), ("4", "4"), ("4", "8")])
+def test_exhaustive_descents_for_every_shape_of_the_grid(eng, ctx, monkeypatch, rj, waves):
+    """Columns per lane (strip width 63 / 127 / 255) and waves per SIMD (how the row units are dealt) change no decision."""
+    for n, seed in ((300, 1), (1000, 2)):
+        xy = rand_instance(n, seed=seed, hi=20000)
+        _, succ0, _ = O.greedy(xy, O.EUC_2D)
+        _check(eng, ctx, monkeypatch, xy, O.EUC_2D, succ0, {"TSP_EXH_RJ": rj, "TSP_EXH_WAVES": waves})
+
+
+@pytest.mark.parametrize("name,wt", [("att532", O.ATT), ("pr299", O.EUC_2D), ("rand600", O.CEIL_2D), ("berlin52", O.EUC_2D), ("rat575", O.CEIL_2D)])
+def test_exhaustive_descents_on_the_three_integer_root_metrics(eng, ctx, monkeypatch, name, wt):
+    xy, _ = load_instance(name)
+    _, succ0, _ = O.greedy(xy, wt)
+    _check(eng, ctx, monkeypatch, xy, wt, succ0)
+    _check(eng, ctx, monkeypatch, xy, wt, random_tour(len(xy), np.random.default_rng(7)))
+
+
+def test_exhaustive_descent_with_ties_and_duplicate_points(eng, ctx, monkeypatch):
+    """A lattice (many pairs share the minimal delta: the first pair in (i < j) NODE order must win, whatever the tour
+    position order in which the lanes meet them) and coincident points (zero-length edges)."""
+    g = np.array([(10 * (k % 17), 10 * (k // 17)) for k in range(17 * 17)], dtype=np.float64)
+    rng = np.random.default_rng(3)
+    for wt in (O.EUC_2D, O.ATT, O.CEIL_2D):
+        _check(eng, ctx, monkeypatch, g, wt, random_tour(len(g), rng))
+    d = rand_instance(200, seed=9, hi=300)
+    d[50:90] = d[10:50]                      # forty duplicate points
+    _check(eng, ctx, monkeypatch, d, O.EUC_2D, random_tour(200, rng))
+
+
+def test_exhaustive_batch_of_tours_and_the_old_tiled_path_agree(eng, ctx, monkeypatch):
+    """grid.z = tour; and TSP_EXH_POS=0 (the tiled k_step executing every delta expression, two distances per pair) gives the
+    same descents."""
+    monkeypatch.setenv("TSP_NO_FILTER", "1")
+    xy = rand_instance(400, seed=11, hi=30000)
+    rng = np.random.default_rng(5)
+    succ = np.stack([random_tour(400, rng) for _ in range(5)])
+    inst = eng.Instance(ctx, xy, O.EUC_2D, 1)
+    rc, s2, o2, st = inst.two_opt(succ, np.zeros(5), mode=eng.BEST, engine=eng.ENGINE_GRID)
+    inst.close()
+    assert rc == 0
+    for b in range(5):
+        _, es, eo, est, _, _ = O.two_opt_best(xy, O.EUC_2D, succ[b])
+        assert (s2[b] == es).all() and o2[b] == eo and st[b]["sweeps"] == est["sweeps"], b
+    s_old, o_old, st_old = _descent(eng, ctx, monkeypatch, xy, O.EUC_2D, succ[0], {"TSP_EXH_POS": "0"}, expect_exh=False)
+    assert (s_old == s2[0]).all() and o_old == o2[0] and st_old["sweeps"] == st[0]["sweeps"]
+
+
+def test_exhaustive_full_descent_of_rand10000_equals_the_golden(eng, ctx, monkeypatch):
+    """BASELINE configs[2] with every delta expression executed: 1 428 sweeps x 49 985 000 pairs (what bench.py times) end in the
+    oracle's tour (hash, cost, sweeps, evaluations, moves, reversal length of its 23-minute CPU descent)."""
+    g = BIG["rand10000_best"]
+    xy, wt = load_instance("rand10000")
+    _, succ0, obj0 = O.greedy(xy, wt)
+    assert obj0 == g["greedy"]["obj"] and O.fnv1a(succ0) == g["greedy"]["hash"]
+    s, o, st = _descent(eng, ctx, monkeypatch, xy, wt, succ0)
+    f = g["final"]
+    assert O.fnv1a(s) == f["hash"] and o == f["cost"]
+    assert {k: st[k] for k in ("sweeps", "evals", "moves", "reversed")} == f["stats"]

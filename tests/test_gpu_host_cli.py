@@ -10,38 +10,11 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from helpers import golden, load_instance, INSTANCES
+from helpers import golden, load_instance, INSTANCES, Instance, Edge, HostInstance   # noqa: F401 (re-exported for other test modules)
 
 pytestmark = pytest.mark.gpu
 REF = golden("reference_results.json")["instances"]
 APB = golden("survey_appendix_b.json")
-
-
-# ---- ctypes view of include/utility.h:113-160 as restated in host/tsp_host.h ---------------------
-class SolMethod(C.Structure):
-    _fields_ = [("id", C.c_int), ("edge_type", C.c_int), ("name", C.c_char_p), ("use_cplex", C.c_int)]
-
-
-class Params(C.Structure):
-    _fields_ = [("file_path", C.c_char_p), ("num_threads", C.c_int), ("time_limit", C.c_int),
-                ("method", SolMethod), ("verbose", C.c_int), ("integer_cost", C.c_int), ("seed", C.c_int),
-                ("perf_prof", C.c_int), ("callback_2opt", C.c_int)]
-
-
-class Edge(C.Structure):
-    _fields_ = [("i", C.c_int), ("j", C.c_int)]
-
-
-class Solution(C.Structure):
-    _fields_ = [("obj_best", C.c_double), ("edges", C.POINTER(Edge)), ("time_to_solve", C.c_double),
-                ("xbest", C.POINTER(C.c_double))]
-
-
-class Instance(C.Structure):
-    _fields_ = [("params", Params), ("name", C.c_char_p), ("comment", C.c_char_p),
-                ("nodes", C.POINTER(C.c_double)), ("num_nodes", C.c_int), ("weight_type", C.c_int),
-                ("num_columns", C.c_long), ("ind", C.POINTER(C.c_int)), ("thread_seeds", C.POINTER(C.c_uint)),
-                ("solution", Solution)]
 
 
 @pytest.fixture(scope="module")
@@ -68,41 +41,11 @@ def host():
     L.tsp_host_tabu.argtypes = [C.POINTER(Instance), C.c_int, C.c_longlong]
     L.tsp_host_genetic.argtypes = [C.POINTER(Instance), C.c_longlong]
     L.tsp_host_genetic_ex.argtypes = [C.POINTER(Instance), C.c_longlong, C.c_double]
+    L.HEU_Grasp_iter.argtypes = [C.POINTER(Instance), C.c_int]
+    L.HEU_2opt_grasp_iter.argtypes = [C.POINTER(Instance)]
+    L.tsp_host_last_grasp_iter_starts.restype = C.c_longlong
     yield L
     L.tsp_host_shutdown()
-
-
-class HostInstance:
-    """Owns the numpy buffers an `instance` points into."""
-
-    def __init__(self, name, integer_cost=1):
-        self.xy, self.wt = load_instance(name)
-        self.n = len(self.xy)
-        self.edges = np.zeros((self.n, 2), dtype=np.int32)
-        self.c = Instance()
-        self.c.params.time_limit = -1
-        self.c.params.integer_cost = integer_cost
-        self.c.params.seed = 123
-        self.c.params.verbose = 0
-        self.c.params.perf_prof = 1
-        self.c.nodes = self.xy.ctypes.data_as(C.POINTER(C.c_double))
-        self.c.num_nodes = self.n
-        self.c.weight_type = self.wt
-        self.c.num_columns = self.n * (self.n - 1) // 2
-        self.c.solution.edges = self.edges.ctypes.data_as(C.POINTER(Edge))
-
-    @property
-    def succ(self):
-        return self.edges[:, 1].copy()
-
-    @property
-    def obj(self):
-        return self.c.solution.obj_best
-
-    def set_tour(self, succ, obj):
-        self.edges[:, 0] = np.arange(self.n)
-        self.edges[:, 1] = succ
-        self.c.solution.obj_best = obj
 
 
 def stats(L):
@@ -212,6 +155,38 @@ def test_multistart_256_matches_golden_table_and_shards(host):
         results.append((cost.value, start.value))
     assert results[0] == (exp["best_true"], exp["best_start"])
     assert min(results[1:]) == results[0]                          # what the all-reduce(min) would return
+
+
+@pytest.mark.parametrize("name", ["berlin52", "att48"])
+def test_grasp_iter_returns_the_best_of_a_prefix_of_the_reference_stream(host, name):
+    """HEU_Grasp_iter (heuristics.c:510-544) is bounded by the wall clock, so WHICH prefix of the seed-123 stream it covers
+    depends on the machine -- but not what it returns for that prefix: the GRASP tour of start k*, the first start with the
+    lowest reported cost among the first 256 m starts (the device builds 256 per clock check where the reference checks per
+    start, :519-525).  m is what the call reports; the oracle walks the same stream for exactly 256 m starts.  Then
+    HEU_2opt_grasp_iter (:559-570) with -t 5 (GRASP budget 5 / 5 = 1 s): its output is alg_2opt of THAT tour, the closing
+    edge GRASP counts twice (:135,:152) still inside the reported cost."""
+    h = HostInstance(name)
+    O.srandom(123)
+    rc = host.HEU_Grasp_iter(C.byref(h.c), 1)
+    starts = host.tsp_host_last_grasp_iter_starts()
+    assert rc == 2 and starts >= 256 and starts % 256 == 0               # TIME_LIMIT_EXCEEDED is the only way out (:522-524)
+    O.srandom(123)
+    es, eo, k_star = O.grasp_iter_prefix(h.xy, h.wt, starts)
+    assert h.obj == eo and (h.succ == es).all() and (h.edges[:, 0] == np.arange(h.n)).all()
+    assert 0 <= k_star < starts
+    # the same through the 2-opt wrapper: whatever prefix THIS call covers, the result is alg_2opt of that prefix's best tour
+    h2 = HostInstance(name)
+    h2.c.params.time_limit = 5
+    O.srandom(123)
+    rc = host.HEU_2opt_grasp_iter(C.byref(h2.c))
+    starts2 = host.tsp_host_last_grasp_iter_starts()
+    assert rc == 0 and starts2 >= 256 and starts2 % 256 == 0
+    O.srandom(123)
+    gs, go, _ = O.grasp_iter_prefix(h2.xy, h2.wt, starts2)
+    _, fs, fo, fst, _ = O.two_opt_first(h2.xy, h2.wt, gs, go)
+    assert h2.obj == fo and (h2.succ == fs).all()
+    assert stats(host) == (fst["sweeps"], fst["evals"], fst["moves"])
+    assert h2.obj == O.succ_cost(h2.xy, h2.wt, h2.succ) + (go - O.succ_cost(h2.xy, h2.wt, gs))   # the double-counted closing edge rides along
 
 
 # ---- the meta-heuristic drivers around the two 2-opt loops (SURVEY 8(f) ranks 1-2) ---------------

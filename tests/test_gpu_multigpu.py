@@ -100,3 +100,165 @@ def test_bench_starts_its_own_ranks_and_runs_the_collectives_over_rccl():
     c4 = out["other_configs"]["config4_att532_grasp256_2opt"]
     assert "tsp_dev_multistart_allreduce" in c4["collectives"] and c4["winner_is_the_reference_winner"]
     assert len(c4["refine_s_per_rank"]) == 1
+
+
+# ---- round 4: the population job of BASELINE configs[4] behind the C host, --fcost through the epilogue, failure agreement ----
+
+def _host_lib():
+    import ctypes as C
+    from tsp_optimization_amd.build import lib_path
+    from tsp_optimization_amd import engine as E
+    from helpers import Instance
+    L = C.CDLL(lib_path("libtsp_host.so"))
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.tsp_host_population_gpus.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, dp, ip, dp, dp, ip, C.POINTER(E.Stats)]
+    L.HEU_2opt_population_multistart.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, C.c_int, dp, ip, dp, ip, C.POINTER(E.Stats)]
+    L.HEU_2opt_grasp_multistart.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, C.c_int, dp, ip]
+    L.tsp_host_multistart_gpus.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, dp, ip, dp]
+    L.tsp_host_multistart_epilogue.argtypes = [C.POINTER(Instance), C.c_int, C.c_int, C.c_int, dp, ip]
+    L.tsp_host_multistart_last_error.restype = C.c_char_p
+    L.tsp_host_genetic_gpus.argtypes = [C.POINTER(Instance), C.c_longlong, C.c_double, C.c_int]
+    L.calc_dist.restype = C.c_double
+    L.calc_dist.argtypes = [C.c_int, C.c_int, C.POINTER(Instance)]
+    return L
+
+
+@pytest.mark.parametrize("how", ["threads_per_gpu", "forced_comm_rank", "one_process"])
+def test_population_128_through_the_c_host_equals_the_golden_table(how, monkeypatch):
+    """BASELINE configs[4] behind the C host (north star: "genetic population members shard ... across the GPUs", "host code
+    stays in C"): 128 random individuals of rand5000 drawn as random_generation draws them (genetic.c:349-364, seed 123), each
+    refined by alg_2opt (:426-443) -- every row of the oracle's 128-row table (cost, tour hash, sweeps, evaluations, moves)
+    and the winner (57357536, individual 9), whose tour is the one that came back through RCCL's broadcast.
+    threads_per_gpu: tsp_host_population_gpus(gpus = 1) = thread + context per GPU, ncclCommInitAll, grouped collectives;
+    forced_comm_rank: HEU_2opt_population_multistart with TSP_FORCE_COMM=1 = the one-process-per-GPU path with one rank
+    (id file, ncclCommInitRank, all-reduce(min), broadcast); one_process: no collective."""
+    import ctypes as C
+    from oracle import oracle as O
+    from tsp_optimization_amd import engine as E
+    from helpers import HostInstance
+    g = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]
+    L = _host_lib()
+    h = HostInstance("rand5000")
+    n, P = h.n, g["population"]
+    costs, succ, st = np.zeros(P), np.zeros((P, n), dtype=np.int32), (E.Stats * P)()
+    cost, who, secs = C.c_double(0), C.c_int(-1), (C.c_double * 1)()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    C.CDLL(None).srandom(g["seed"])
+    if how == "threads_per_gpu":
+        rc = L.tsp_host_population_gpus(C.byref(h.c), P, 1, C.byref(cost), C.byref(who), secs, costs.ctypes.data_as(dp), succ.ctypes.data_as(ip), st)
+        assert secs[0] > 0
+    else:
+        if how == "forced_comm_rank":
+            monkeypatch.setenv("TSP_FORCE_COMM", "1")
+        else:
+            monkeypatch.delenv("TSP_FORCE_COMM", raising=False)
+        for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"):
+            monkeypatch.delenv(k, raising=False)
+        rc = L.HEU_2opt_population_multistart(C.byref(h.c), P, 0, 1, C.byref(cost), C.byref(who), costs.ctypes.data_as(dp), succ.ctypes.data_as(ip), st)
+    assert rc == 0
+    for k, row in enumerate(g["individuals"]):
+        assert costs[k] == row["cost"] and O.fnv1a(succ[k]) == row["hash"], k
+        assert (st[k].sweeps, st[k].evals, st[k].moves, st[k].reversed) == (row["sw"], row["ev"], row["mv"], row["reversed"]), k
+    best = min(g["individuals"], key=lambda r: (r["cost"], r["k"]))
+    assert (best["cost"], best["k"]) == (57357536, 9)
+    assert (cost.value, who.value) == (57357536, 9) and h.obj == 57357536 and O.fnv1a(h.succ) == best["hash"]
+    assert (h.edges[:, 0] == np.arange(n)).all()
+    L.tsp_host_shutdown()
+
+
+def _rand_tsplib(tmp_path, n):
+    from helpers import rand_instance
+    xy = rand_instance(n)
+    f = tmp_path / ("rand%d.tsp" % n)
+    f.write_text("NAME : rand%d\nTYPE : TSP\nDIMENSION : %d\nEDGE_WEIGHT_TYPE : EUC_2D\nNODE_COORD_SECTION\n" % (n, n) +
+                 "".join("%d %d %d\n" % (k + 1, x, y) for k, (x, y) in enumerate(xy)) + "EOF\n")
+    return str(f)
+
+
+@pytest.mark.parametrize("how", ["one_process", "forced_comm_rank", "threads_per_gpu"])
+def test_cli_population_multi_prints_the_golden_winner(how, tmp_path):
+    """`tsp -f rand5000.tsp -method 2OPT_POP_MULTI -starts 128 -seed 123 [-gpus 1]`: the CLI method of configs[4], three ways."""
+    args = ["-f", _rand_tsplib(tmp_path, 5000), "-method", "2OPT_POP_MULTI", "-starts", "128", "-seed", "123", "--perfprof", "-verbose", "-1"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TSP_FORCE_COMM"):
+        env.pop(k, None)
+    if how == "forced_comm_rank":
+        env["TSP_FORCE_COMM"] = "1"
+    if how == "threads_per_gpu":
+        args += ["-gpus", "1"]
+    assert _cli(args, env) == "57357536.00"
+
+
+@pytest.mark.parametrize("how", ["threads_per_gpu", "forced_comm_rank"])
+def test_fcost_multistart_goes_through_the_two_reduction_epilogue(how, monkeypatch):
+    """--fcost (src/utility.c:285): costs are doubles, `< bestobj` (heuristics.c:534) still decides.  att532 x 256 GRASP starts
+    + alg_2opt with integer_cost = 0 through RCCL: min of the double, then min of the start among its holders, then the
+    broadcast -- cost bit-identical to the oracle's float table (start 67), tour = that row's."""
+    import ctypes as C
+    from oracle import oracle as O
+    from helpers import HostInstance
+    g = golden("oracle_vectors_fcost.json")
+    L = _host_lib()
+    h = HostInstance("att532", integer_cost=0)
+    cost, start = C.c_double(0), C.c_int(-1)
+    C.CDLL(None).srandom(123)
+    if how == "threads_per_gpu":
+        assert L.tsp_host_multistart_gpus(C.byref(h.c), 256, 1, C.byref(cost), C.byref(start), None) == 0
+    else:
+        monkeypatch.setenv("TSP_FORCE_COMM", "1")
+        for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"):
+            monkeypatch.delenv(k, raising=False)
+        assert L.HEU_2opt_grasp_multistart(C.byref(h.c), 256, 0, 1, C.byref(cost), C.byref(start)) == 0
+    best = g["best"]
+    row = g["starts"][best["k"]]
+    assert (cost.value.hex(), start.value) == (best["cost_hex"], best["k"]) and best["k"] == 67
+    assert O.fnv1a(h.succ) == row["hash"] and h.obj == cost.value
+    assert cost.value != int(cost.value)                             # really a cost the packed word cannot carry
+    L.tsp_host_shutdown()
+
+
+def test_cli_fcost_multistart_prints_the_float_winner():
+    f = os.path.join(INSTANCES, "att532.tsp")
+    env = dict(os.environ, TSP_FORCE_COMM="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = _cli(["-f", f, "-method", "2OPT_GRASP_MULTI", "-starts", "256", "-seed", "123", "--fcost", "--perfprof", "-verbose", "-1"], env)
+    assert out == "%0.2f" % golden("oracle_vectors_fcost.json")["best"]["cost"]
+
+
+def test_epilogue_over_rccl_carries_a_failed_shard_to_every_rank(monkeypatch):
+    """The failure agreement on the real transport (one rank: what a 1-GPU box can form): a shard that failed is contributed
+    to ncclAllReduce as the value that wins the minimum; the epilogue returns TSP_HOST_E_PEER instead of exiting before the
+    collective.  (World 2 over gloo: tests/test_cpu_epilogue.py.)"""
+    import ctypes as C
+    from helpers import HostInstance
+    L = _host_lib()
+    for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    for ic in (1, 0):
+        h = HostInstance("berlin52", integer_cost=ic)
+        assert L.calc_dist(0, 1, C.byref(h.c)) > 0                    # opens this process's device context
+        h.set_tour(np.roll(np.arange(h.n, dtype=np.int32), -1), 123.0)
+        best, bk = C.c_double(123.0), C.c_int(3)
+        assert L.tsp_host_multistart_epilogue(C.byref(h.c), 0, 1, 0, C.byref(best), C.byref(bk)) == 0
+        assert (best.value, bk.value, h.obj) == (123.0, 3, 123.0)
+        assert L.tsp_host_multistart_epilogue(C.byref(h.c), 0, 1, -2, C.byref(best), C.byref(bk)) == -7
+        assert b"shard failed" in L.tsp_host_multistart_last_error()
+    L.tsp_host_shutdown()
+
+
+def test_genetic_mutation3_batch_over_gpus_matches_oracle():
+    """tsp_host_genetic_gpus(..., gpus = 1): the offspring that drew mutation 3 (genetic.c:426-443) are refined by per-GPU
+    worker threads with their own context and instance (the CLI's `-method GENETIC -gpus G`); same incumbent as the oracle GA."""
+    import ctypes as C
+    from oracle import oracle as O
+    from helpers import HostInstance
+    L = _host_lib()
+    h = HostInstance("berlin52")
+    h.c.params.time_limit = 600
+    O.srandom(123)
+    rc = L.tsp_host_genetic_gpus(C.byref(h.c), 25, 0.5, 1)
+    O.srandom(123)
+    es, eo = O.genetic(h.xy, h.wt, 25, two_opt_prob=0.5)
+    assert rc == 0 and h.obj == eo and (h.succ == es).all()
+    L.tsp_host_shutdown()

@@ -3,8 +3,10 @@
 // (the generalisation of HEU_Grasp_iter's "keep the best start", src/heuristics.c:510-544).
 //
 // The path shards across tours only, so these two latency-bound collectives (8 bytes, 4n bytes) are the only traffic
-// over xGMI.  librccl is opened lazily (dlopen) the first time a communicator is asked for: a single-GPU caller never
-// pays for loading it, and libtsp_hip.so has no link-time dependency on it.  Two ways to form the communicator:
+// over xGMI (two reductions when the costs are not integers: min of the double, then min of the start id among its holders).
+// librccl is opened lazily (dlopen) the first time a communicator is asked for: a single-GPU caller never pays for loading it,
+// and libtsp_hip.so has neither a link-time nor a build-time dependency on it (<rccl/rccl.h> is used when present, see
+// below).  Every collective waits for its peers with a timeout (comm_wait).  Two ways to form the communicator:
 //   tsp_dev_comm_init_rank   one process per GPU (torchrun / mpirun style): rank 0 calls tsp_dev_comm_unique_id and hands
 //                            the 128 bytes to the other ranks by any side channel (libtsp_host.so: a file);
 //   tsp_dev_comm_init_all    one process, several devices (ncclCommInitAll); the collectives of all its communicators are
@@ -12,8 +14,25 @@
 #include "tsp_internal.hpp"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <time.h>
 #include <unistd.h>
+
+// RCCL is reached through dlopen / dlsym only, so its header is needed for nothing but a handful of types and enumerators.
+// A ROCm install without the rccl development package still builds this library (every tsp_dev_comm_* entry then works
+// as long as librccl.so.1 itself can be opened at run time); where the header exists it is used and checks the local values.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+static_assert(ncclInt32 == 2 && ncclInt64 == 4 && ncclFloat64 == 8 && ncclMin == 3 && ncclSuccess == 0,
+              "RCCL's enumerators are not the ones this file declares for header-less builds");
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt32 = 2, ncclInt64 = 4, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclMin = 3 } ncclRedOp_t;
+}
+#endif
 
 #include <mutex>
 
@@ -25,6 +44,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -60,6 +80,7 @@ void rccl_open() {
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
     g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(sym("ncclGetVersion"));
     g_rccl.ok = all;
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.handle, "ncclCommAbort"));   // optional
 }
 
 const Rccl *rccl() {
@@ -90,10 +111,13 @@ struct StdoutToStderr {
 };
 
 struct tsp_dev_comm {
-    tsp_dev_ctx *ctx = nullptr;
+    tsp_dev_ctx *ctx = nullptr;     // must outlive the communicator; device and stream are kept by value for the teardown
+    int device = 0;
+    hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
-    long long *d_word = nullptr;    // the packed best of this rank, reduced in place
+    bool broken = false;            // a collective timed out or failed: the communicator is aborted, not destroyed
+    long long *d_word = nullptr;    // the packed best (or, as its bit pattern, the double cost) of this rank, reduced in place
     int *d_tour = nullptr;          // broadcast buffer, grown on demand
     size_t tour_cap = 0;
 };
@@ -108,19 +132,113 @@ struct tsp_dev_comm {
         }                                                                                               \
     } while (0)
 
+// Inside ncclGroupStart / ncclGroupEnd: remember the first failure and keep going, so that the group is always closed (a
+// return from between the two would leave this thread's group open and every later RCCL call silently queued).
+#define TSP_NCCL_NOTE(rcvar, expr)                                                                      \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess && (rcvar) == TSP_OK) {                                                  \
+            snprintf(g_comm_error, sizeof g_comm_error, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr,   \
+                     R->GetErrorString(r__));                                                           \
+            (rcvar) = TSP_DEV_E_COMM;                                                                   \
+        }                                                                                               \
+    } while (0)
+
 namespace {
 int comm_alloc(tsp_dev_comm *c) {
-    TSP_HIP_TRY(hipSetDevice(c->ctx->device));
+    TSP_HIP_TRY(hipSetDevice(c->device));
     TSP_HIP_TRY(hipMalloc(&c->d_word, sizeof(long long)));
     return TSP_OK;
 }
 int comm_tour_buf(tsp_dev_comm *c, size_t n) {
     if (n <= c->tour_cap) return TSP_OK;
-    TSP_HIP_TRY(hipSetDevice(c->ctx->device));
-    TSP_HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    TSP_HIP_TRY(hipSetDevice(c->device));
+    TSP_HIP_TRY(hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_tour); c->d_tour = nullptr; c->tour_cap = 0;
     TSP_HIP_TRY(hipMalloc(&c->d_tour, sizeof(int) * n));
     c->tour_cap = n;
+    return TSP_OK;
+}
+
+double comm_timeout_s() {
+    static const double t = [] {
+        const char *e = getenv("TSP_COMM_TIMEOUT_S");
+        const double v = e && *e ? atof(e) : 300.0;
+        return v > 0 ? v : 300.0;
+    }();
+    return t;
+}
+
+// Wait for the collective queued on the communicator's stream, but not for ever: RCCL has no timeout of its own, and a peer
+// that died before it entered the collective would leave this rank in hipStreamSynchronize until somebody kills it.  After
+// TSP_COMM_TIMEOUT_S (300) seconds the communicator is aborted and the call fails with TSP_DEV_E_COMM, so that the caller
+// exits non-zero like the peer did.
+int comm_wait(tsp_dev_comm *c, const char *what) {
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    long spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return TSP_OK;
+        if (q != hipErrorNotReady) { TSP_HIP_TRY(q); }
+        if (++spins > 2000) { timespec nap = {0, 200 * 1000}; nanosleep(&nap, nullptr); }   // the usual wait is tens of microseconds
+        if ((spins & 255) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double el = double(t1.tv_sec - t0.tv_sec) + 1e-9 * double(t1.tv_nsec - t0.tv_nsec);
+            if (el > comm_timeout_s()) {
+                snprintf(g_comm_error, sizeof g_comm_error, "rank %d of %d: %s did not complete within %.0f s (a peer never entered "
+                         "it?); communicator aborted", c->rank, c->world, what, comm_timeout_s());
+                if (g_rccl.ok && g_rccl.CommAbort && c->comm) { (void)g_rccl.CommAbort(c->comm); c->comm = nullptr; }
+                c->broken = true;
+                return TSP_DEV_E_COMM;
+            }
+        }
+    }
+}
+
+// all-reduce(min) of one 8-byte word per rank (int64 or double); every rank receives the minimum
+int allreduce_word(tsp_dev_comm *c, const void *local, void *best, ncclDataType_t type) {
+    if (!c || !best || c->broken) return TSP_DEV_E_ARG;
+    const Rccl *R = rccl();
+    if (!R) return TSP_DEV_E_COMM;
+    TSP_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    long long w;
+    memcpy(&w, local, sizeof w);
+    TSP_HIP_TRY(hipMemcpyAsync(c->d_word, &w, sizeof w, hipMemcpyHostToDevice, s));
+    TSP_NCCL_TRY(R->AllReduce(c->d_word, c->d_word, 1, type, ncclMin, c->comm, s));
+    TSP_HIP_TRY(hipMemcpyAsync(&w, c->d_word, sizeof w, hipMemcpyDeviceToHost, s));
+    int rc = comm_wait(c, "the all-reduce(min)");
+    if (rc) return rc;
+    memcpy(best, &w, sizeof w);
+    return TSP_OK;
+}
+
+int allreduce_word_group(tsp_dev_comm *const *cs, int ndev, const void *local, void *best, ncclDataType_t type) {
+    if (!cs || !local || !best || ndev < 1 || ndev > 64) return TSP_DEV_E_ARG;
+    const Rccl *R = rccl();
+    if (!R) return TSP_DEV_E_COMM;
+    for (int k = 0; k < ndev; ++k) {
+        if (!cs[k] || cs[k]->world != ndev || cs[k]->broken) return TSP_DEV_E_ARG;
+        TSP_HIP_TRY(hipSetDevice(cs[k]->device));
+        long long w;
+        memcpy(&w, static_cast<const char *>(local) + 8 * (size_t)k, sizeof w);
+        TSP_HIP_TRY(hipMemcpy(cs[k]->d_word, &w, sizeof w, hipMemcpyHostToDevice));
+    }
+    int rc = TSP_OK;
+    TSP_NCCL_TRY(R->GroupStart());
+    for (int k = 0; k < ndev; ++k)
+        TSP_NCCL_NOTE(rc, R->AllReduce(cs[k]->d_word, cs[k]->d_word, 1, type, ncclMin, cs[k]->comm, cs[k]->stream));
+    TSP_NCCL_NOTE(rc, R->GroupEnd());
+    if (rc) return rc;
+    for (int k = 0; k < ndev; ++k) {
+        TSP_HIP_TRY(hipSetDevice(cs[k]->device));
+        rc = comm_wait(cs[k], "the grouped all-reduce(min)");
+        if (rc) return rc;
+        long long w = 0;
+        TSP_HIP_TRY(hipMemcpy(&w, cs[k]->d_word, sizeof w, hipMemcpyDeviceToHost));
+        memcpy(static_cast<char *>(best) + 8 * (size_t)k, &w, sizeof w);
+    }
     return TSP_OK;
 }
 }  // namespace
@@ -148,7 +266,7 @@ int tsp_dev_comm_init_rank(tsp_dev_ctx *ctx, int world, int rank, const char *id
     if (!R) return TSP_DEV_E_COMM;
     TSP_HIP_TRY(hipSetDevice(ctx->device));
     tsp_dev_comm *c = new tsp_dev_comm();
-    c->ctx = ctx; c->rank = rank; c->world = world;
+    c->ctx = ctx; c->device = ctx->device; c->stream = ctx->stream; c->rank = rank; c->world = world;
     struct Guard { tsp_dev_comm *c; ~Guard() { if (c) tsp_dev_comm_destroy(c); } } guard{c};
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
@@ -181,7 +299,7 @@ int tsp_dev_comm_init_all(tsp_dev_ctx *const *ctxs, int ndev, tsp_dev_comm **out
     }
     for (int k = 0; k < ndev; ++k) {
         tsp_dev_comm *c = new tsp_dev_comm();
-        c->ctx = ctxs[k]; c->comm = comms[k]; c->rank = k; c->world = ndev;
+        c->ctx = ctxs[k]; c->device = ctxs[k]->device; c->stream = ctxs[k]->stream; c->comm = comms[k]; c->rank = k; c->world = ndev;
         out[k] = c;
     }
     for (int k = 0; k < ndev; ++k) {
@@ -191,10 +309,12 @@ int tsp_dev_comm_init_all(tsp_dev_ctx *const *ctxs, int ndev, tsp_dev_comm **out
     return TSP_OK;
 }
 
+// The context the communicator was formed on must still be open (its stream carries the collectives): destroy the
+// communicator first, then tsp_dev_close.  Nothing of the context is dereferenced here -- device and stream were copied.
 void tsp_dev_comm_destroy(tsp_dev_comm *c) {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipSetDevice(c->device);
+    if (!c->broken) (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.ok) (void)g_rccl.CommDestroy(c->comm);
     (void)hipFree(c->d_word); (void)hipFree(c->d_tour);
     delete c;
@@ -218,28 +338,21 @@ int tsp_dev_multistart_pack(double cost, int start_id, int64_t *packed) {
 }
 
 int tsp_dev_multistart_allreduce(tsp_dev_comm *c, int64_t packed_local, int64_t *packed_best) {
-    if (!c || !packed_best) return TSP_DEV_E_ARG;
-    const Rccl *R = rccl();
-    if (!R) return TSP_DEV_E_COMM;
-    TSP_HIP_TRY(hipSetDevice(c->ctx->device));
-    hipStream_t s = c->ctx->stream;
-    long long w = packed_local;
-    TSP_HIP_TRY(hipMemcpyAsync(c->d_word, &w, sizeof w, hipMemcpyHostToDevice, s));
-    TSP_NCCL_TRY(R->AllReduce(c->d_word, c->d_word, 1, ncclInt64, ncclMin, c->comm, s));
-    TSP_HIP_TRY(hipMemcpyAsync(&w, c->d_word, sizeof w, hipMemcpyDeviceToHost, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
-    *packed_best = w;
-    return TSP_OK;
+    return allreduce_word(c, &packed_local, packed_best, ncclInt64);
+}
+
+int tsp_dev_multistart_allreduce_f64(tsp_dev_comm *c, double cost_local, double *cost_best) {
+    return allreduce_word(c, &cost_local, cost_best, ncclFloat64);
 }
 
 int tsp_dev_multistart_bcast_tour(tsp_dev_comm *c, int root, int *succ, int succ_stride, int n) {
-    if (!c || !succ || n < 1 || succ_stride < 1 || root < 0 || root >= c->world) return TSP_DEV_E_ARG;
+    if (!c || !succ || n < 1 || succ_stride < 1 || root < 0 || root >= c->world || c->broken) return TSP_DEV_E_ARG;
     const Rccl *R = rccl();
     if (!R) return TSP_DEV_E_COMM;
     int rc = comm_tour_buf(c, (size_t)n);
     if (rc) return rc;
-    TSP_HIP_TRY(hipSetDevice(c->ctx->device));
-    hipStream_t s = c->ctx->stream;
+    TSP_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
     std::vector<int> h((size_t)n);
     if (c->rank == root) {
         for (int v = 0; v < n; ++v) h[v] = succ[(size_t)v * succ_stride];
@@ -247,34 +360,19 @@ int tsp_dev_multistart_bcast_tour(tsp_dev_comm *c, int root, int *succ, int succ
     }
     TSP_NCCL_TRY(R->Broadcast(c->d_tour, c->d_tour, (size_t)n, ncclInt32, root, c->comm, s));
     TSP_HIP_TRY(hipMemcpyAsync(h.data(), c->d_tour, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
-    TSP_HIP_TRY(hipStreamSynchronize(s));
+    rc = comm_wait(c, "the broadcast of the winner's tour");
+    if (rc) return rc;
     if (c->rank != root)
         for (int v = 0; v < n; ++v) succ[(size_t)v * succ_stride] = h[v];
     return TSP_OK;
 }
 
 int tsp_dev_multistart_allreduce_group(tsp_dev_comm *const *cs, int ndev, const int64_t *packed_local, int64_t *packed_best) {
-    if (!cs || !packed_local || !packed_best || ndev < 1 || ndev > 64) return TSP_DEV_E_ARG;
-    const Rccl *R = rccl();
-    if (!R) return TSP_DEV_E_COMM;
-    for (int k = 0; k < ndev; ++k) {
-        if (!cs[k] || cs[k]->world != ndev) return TSP_DEV_E_ARG;
-        TSP_HIP_TRY(hipSetDevice(cs[k]->ctx->device));
-        long long w = packed_local[k];
-        TSP_HIP_TRY(hipMemcpy(cs[k]->d_word, &w, sizeof w, hipMemcpyHostToDevice));
-    }
-    TSP_NCCL_TRY(R->GroupStart());
-    for (int k = 0; k < ndev; ++k)
-        TSP_NCCL_TRY(R->AllReduce(cs[k]->d_word, cs[k]->d_word, 1, ncclInt64, ncclMin, cs[k]->comm, cs[k]->ctx->stream));
-    TSP_NCCL_TRY(R->GroupEnd());
-    for (int k = 0; k < ndev; ++k) {
-        TSP_HIP_TRY(hipSetDevice(cs[k]->ctx->device));
-        TSP_HIP_TRY(hipStreamSynchronize(cs[k]->ctx->stream));
-        long long w = 0;
-        TSP_HIP_TRY(hipMemcpy(&w, cs[k]->d_word, sizeof w, hipMemcpyDeviceToHost));
-        packed_best[k] = w;
-    }
-    return TSP_OK;
+    return allreduce_word_group(cs, ndev, packed_local, packed_best, ncclInt64);
+}
+
+int tsp_dev_multistart_allreduce_f64_group(tsp_dev_comm *const *cs, int ndev, const double *cost_local, double *cost_best) {
+    return allreduce_word_group(cs, ndev, cost_local, cost_best, ncclFloat64);
 }
 
 int tsp_dev_multistart_bcast_tour_group(tsp_dev_comm *const *cs, int ndev, int root, const int *succ_root, int succ_stride,
@@ -287,21 +385,24 @@ int tsp_dev_multistart_bcast_tour_group(tsp_dev_comm *const *cs, int ndev, int r
     std::vector<int> h((size_t)n);
     for (int v = 0; v < n; ++v) h[v] = succ_root[(size_t)v * succ_stride];
     for (int k = 0; k < ndev; ++k) {
-        if (!cs[k] || cs[k]->world != ndev) return TSP_DEV_E_ARG;
+        if (!cs[k] || cs[k]->world != ndev || cs[k]->broken) return TSP_DEV_E_ARG;
         int rc = comm_tour_buf(cs[k], (size_t)n);
         if (rc) return rc;
     }
-    TSP_HIP_TRY(hipSetDevice(cs[root]->ctx->device));
+    TSP_HIP_TRY(hipSetDevice(cs[root]->device));
     TSP_HIP_TRY(hipMemcpy(cs[root]->d_tour, h.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    int rc = TSP_OK;
     TSP_NCCL_TRY(R->GroupStart());
     for (int k = 0; k < ndev; ++k)
-        TSP_NCCL_TRY(R->Broadcast(cs[k]->d_tour, cs[k]->d_tour, (size_t)n, ncclInt32, root, cs[k]->comm, cs[k]->ctx->stream));
-    TSP_NCCL_TRY(R->GroupEnd());
+        TSP_NCCL_NOTE(rc, R->Broadcast(cs[k]->d_tour, cs[k]->d_tour, (size_t)n, ncclInt32, root, cs[k]->comm, cs[k]->stream));
+    TSP_NCCL_NOTE(rc, R->GroupEnd());
+    if (rc) return rc;
     for (int k = 0; k < ndev; ++k) {
-        TSP_HIP_TRY(hipSetDevice(cs[k]->ctx->device));
-        TSP_HIP_TRY(hipStreamSynchronize(cs[k]->ctx->stream));
+        TSP_HIP_TRY(hipSetDevice(cs[k]->device));
+        rc = comm_wait(cs[k], "the grouped broadcast of the winner's tour");
+        if (rc) return rc;
     }
-    TSP_HIP_TRY(hipSetDevice(cs[read_back_rank]->ctx->device));
+    TSP_HIP_TRY(hipSetDevice(cs[read_back_rank]->device));
     TSP_HIP_TRY(hipMemcpy(h.data(), cs[read_back_rank]->d_tour, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     for (int v = 0; v < n; ++v) succ_out[v] = h[v];
     return TSP_OK;

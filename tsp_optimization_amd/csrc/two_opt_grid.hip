@@ -12,6 +12,9 @@
 //   two_opt_sweep.hpp  k_move_recs + k_sweep   best improvement on sqrt metrics: nodes ranked along a Hilbert
 //                                  curve, whole 64 x 64 blocks of pairs decided by the box form of the new-edge bound.
 //   two_opt_first.hpp  k_first     first improvement: small fixed grid, moves carried out of place by the next launch.
+//   two_opt_exh.hpp    k_move_pos + k_exh      best improvement with EVERY delta expression executed (TSP_NO_FILTER=1 on the
+//                                  integer-coordinate metrics; bench.py's timed region): tour-position order, one new
+//                                  distance per pair.
 //   two_opt_step.hpp               what they share: arguments, in-launch hand-off, MoveView, apply_step.
 // The two selection rules:
 //   FIRST  = alg_2opt       (src/heuristics.c:438-502): first improving pair after the cursor in
@@ -24,6 +27,7 @@
 // The pair (i,j) always denotes removing (i,succ i) and (j,succ j) and reversing the FORWARD path
 // succ(i)..j (src/utility.c:708-717): that path is the cyclic position range pos[i]+1 .. pos[j],
 // so reversing exactly that range keeps succ() identical to the reference's after every move.
+#include "two_opt_exh.hpp"
 #include "two_opt_first.hpp"
 #include "two_opt_step.hpp"
 #include "two_opt_sweep.hpp"
@@ -198,6 +202,12 @@ bool sorted_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
     return tabu ? (t->tabu_list_run && sorted_sweep_possible(t) && t->n >= 8) : sorted_sweep(t);
 }
 
+// BEST sweeps of this handle execute every delta expression through k_move_pos + k_exh (bounds off, integer-coordinate metric)
+bool exh_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
+    return mode == TSP_2OPT_BEST && !tabu && t->exh_blocks > 0 && t->d_pxy && t->inst->filter_margin > 1e299 &&
+           (t->inst->wtype == WT_EUC_2D_ICOORD || t->inst->wtype == WT_CEIL_2D_ICOORD || t->inst->wtype == WT_ATT_ICOORD);
+}
+
 constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: the dense scan (k_step<TABU>)
 
 // Before a run with a list: bring the handle's list of non-zero stamps up to date (a scan after the host wrote
@@ -274,6 +284,19 @@ template <int WT, bool INT>
 int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int tenure) {
     hipStream_t s = t->inst->ctx->stream;
     StepArgs a = make_args(t, mode, tabu, iter, tenure);
+    if constexpr (exh_metric<WT>()) {
+        if (exh_run(t, mode, tabu)) {
+            hipLaunchKernelGGL((k_move_pos<WT, INT>), dim3((t->n + kExhPad + kScanThreads - 1) / kScanThreads, t->B), dim3(kScanThreads), 0, s,
+                               t->inst->d_coord, t->d_order, t->d_pos, t->d_order2, t->d_pos2, t->d_state, t->d_pxy, t->d_pe, t->d_pid, t->n);
+            a.flat_slots = t->exh_blocks;
+            const ExhArgs x{t->d_pxy, t->d_pe, t->d_pid, t->exh_blocks * (kScanThreads / 64)};
+            const dim3 g(t->exh_blocks, 1, t->B);
+            if (t->exh_rj == 4) hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), 0, s, a, x);
+            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), 0, s, a, x);
+            else hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), 0, s, a, x);
+            return TSP_OK;
+        }
+    }
     if constexpr (has_root_filter<WT>()) {
         if (sorted_run(t, mode, tabu)) {
             a.recs = t->d_rec;
@@ -431,7 +454,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
     }
     if (tabu && t->tabu_list_run)   // the sweeps counted every non-adjacent pair; the skipped ones come off
         hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, s, t->d_state, tabu->d_tabu_pairs);
-    if (sorted_run(t, mode, tabu) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
+    if (sorted_run(t, mode, tabu) || exh_run(t, mode, tabu) || (mode == TSP_2OPT_FIRST && !t->first_v1)) {
         launch_flush(t);
         TSP_HIP_TRY(hipGetLastError());
         if (sync == 1) TSP_HIP_TRY(hipStreamSynchronize(s));   // sync == 2: the caller queues more work and waits once
@@ -786,6 +809,19 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         TSP_HIP_TRY(hipMalloc(&t->d_gmax, (size_t)B * (inst->ng + 1) * sizeof(double)));
 
     }
+    if (inst->filter_margin > 1e299 && TSP_SW(inst, EXH_POS, 1) && inst->n >= 5 &&
+        (inst->wtype == WT_EUC_2D_ICOORD || inst->wtype == WT_CEIL_2D_ICOORD || inst->wtype == WT_ATT_ICOORD)) {
+        // the exhaustive sweep in position order (two_opt_exh.hpp): EXH_WAVES waves per SIMD of one tour's grid, all resident
+        const int waves = std::max(1, std::min(8, TSP_SW(inst, EXH_WAVES, 4)));
+        t->exh_blocks = std::max(1, std::min(2048, inst->ctx->num_cus * waves / std::max(1, B > 4 ? 4 : B)));
+        const int rj = TSP_SW(inst, EXH_RJ, 2);
+        t->exh_rj = rj == 4 ? 4 : (rj == 1 ? 1 : 2);
+        t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->exh_blocks);
+        const size_t pn = (size_t)B * (inst->n + kExhPad);
+        TSP_HIP_TRY(hipMalloc(&t->d_pxy, pn * sizeof(double2)));
+        TSP_HIP_TRY(hipMalloc(&t->d_pe, pn * sizeof(int)));
+        TSP_HIP_TRY(hipMalloc(&t->d_pid, pn * sizeof(int)));
+    }
     TSP_HIP_TRY(hipMalloc(&t->d_cl_ticket, cl_words * sizeof(int)));
     TSP_HIP_TRY(hipMemset(t->d_cl_ticket, 0, cl_words * sizeof(int)));   // every launch leaves them at zero
     TSP_HIP_TRY(hipMalloc(&t->d_order, bn * sizeof(int)));
@@ -818,6 +854,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_state_base); (void)hipFree(t->d_partial); (void)hipFree(t->d_slot_evals); (void)hipFree(t->d_ticket); (void)hipFree(t->d_rec);
     (void)hipFree(t->d_gmax); (void)hipFree(t->d_order2); (void)hipFree(t->d_pos2); (void)hipFree(t->d_pairtab); (void)hipFree(t->d_cl_ticket);
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
+    (void)hipFree(t->d_pxy); (void)hipFree(t->d_pe); (void)hipFree(t->d_pid);
     (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab); (void)hipFree(t->d_cl_stats);
     (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result); (void)hipHostFree(t->h_cl_err);
     (void)hipHostFree(t->h_state);
@@ -937,7 +974,7 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     for (int r = 0; r < reps; ++r) launch_step_rt(t, TSP_2OPT_BEST, nullptr, 0, 0);   // back to back on the engine's stream
     TSP_HIP_TRY(hipEventRecord(e1, s));
     TSP_HIP_TRY(hipEventSynchronize(e1));
-    if (sorted_sweep(t)) { launch_flush(t); TSP_HIP_TRY(hipStreamSynchronize(s)); }
+    if (sorted_sweep(t) || exh_run(t, TSP_2OPT_BEST, nullptr)) { launch_flush(t); TSP_HIP_TRY(hipStreamSynchronize(s)); }
     {
         float ms = 0.f;
         TSP_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -946,6 +983,20 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (mean_ms) *mean_ms = (float)(total / reps);
     if (evals_per_launch) *evals_per_launch = ((int64_t)n * (n - 1) / 2 - n) * t->B;
+    return TSP_OK;
+}
+
+int tsp_dev_tours_describe(tsp_dev_tours *t, int mode, char *buf, int cap) {
+    if (!t || !buf || cap < 1 || (mode != TSP_2OPT_FIRST && mode != TSP_2OPT_BEST)) return TSP_DEV_E_ARG;
+    if (exh_run(t, mode, nullptr))
+        snprintf(buf, (size_t)cap, "k_move_pos + k_exh<RJ=%d> x %d workgroups (every delta expression, tour-position order)", t->exh_rj, t->exh_blocks);
+    else if (sorted_run(t, mode, nullptr))
+        snprintf(buf, (size_t)cap, "k_move_recs + k_sweep x %d workgroups (sorted sweep, box bound)", t->sweep_blocks);
+    else if (mode == TSP_2OPT_BEST)
+        snprintf(buf, (size_t)cap, "%sk_step<BEST> (tiled sweep%s)", t->use_recs && t->n >= 4096 ? "k_recs + " : "",
+                 t->inst->filter_margin > 1e299 ? ", every delta expression" : ", bound tiers");
+    else
+        snprintf(buf, (size_t)cap, "%s", t->first_v1 ? "k_step<FIRST>" : "k_first");
     return TSP_OK;
 }
 

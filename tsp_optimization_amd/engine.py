@@ -87,6 +87,7 @@ def lib():
         L.tsp_dev_tours_snapshot.argtypes = [vp]
         L.tsp_dev_tours_restore.argtypes = [vp]
         L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+        L.tsp_dev_tours_describe.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
         L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
         L.tsp_dev_comm_last_error.restype = C.c_char_p
         L.tsp_dev_comm_unique_id.argtypes = [C.c_char_p]
@@ -97,6 +98,8 @@ def lib():
         L.tsp_dev_comm_info.argtypes = [vp, ip, ip, ip]
         L.tsp_dev_multistart_pack.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_int64)]
         L.tsp_dev_multistart_allreduce.argtypes = [vp, C.c_int64, C.POINTER(C.c_int64)]
+        L.tsp_dev_multistart_allreduce_f64.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+        L.tsp_dev_multistart_allreduce_f64_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.tsp_dev_multistart_bcast_tour.argtypes = [vp, C.c_int, ip, C.c_int, C.c_int]
         L.tsp_dev_multistart_allreduce_group.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.tsp_dev_multistart_bcast_tour_group.argtypes = [C.POINTER(vp), C.c_int, C.c_int, ip, C.c_int, C.c_int, C.c_int, ip]
@@ -111,12 +114,13 @@ EXPORTED = [
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
-    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best",
+    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best", "tsp_dev_tours_describe",
     "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
     "tsp_dev_comm_last_error", "tsp_dev_comm_available", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
     "tsp_dev_comm_info", "tsp_dev_multistart_pack", "tsp_dev_multistart_allreduce", "tsp_dev_multistart_bcast_tour",
     "tsp_dev_multistart_allreduce_group", "tsp_dev_multistart_bcast_tour_group",
+    "tsp_dev_multistart_allreduce_f64", "tsp_dev_multistart_allreduce_f64_group",
 ]
 
 COMM_ID_BYTES = 128
@@ -351,6 +355,12 @@ class Tours:
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
         return rc, bool(done.value)
 
+    def describe(self, mode):
+        """The kernels one GRID-engine step of `mode` launches for this handle."""
+        buf = C.create_string_buffer(256)
+        _check(lib().tsp_dev_tours_describe(self._h, mode, buf, 256))
+        return buf.value.decode()
+
     def run_engine(self, mode, engine=ENGINE_AUTO, max_steps=-1, time_limit=-1.0):
         """Resident tours on a chosen engine, waits for completion.  -> (status, all_done)"""
         done = C.c_int(0)
@@ -457,6 +467,12 @@ class Comm:
     def allreduce_min(self, packed):
         out = C.c_int64(0)
         _check(lib().tsp_dev_multistart_allreduce(self._h, int(packed), C.byref(out)))
+        return out.value
+
+    def allreduce_min_f64(self, cost):
+        """all-reduce(min) of one double per rank (costs the packed word cannot carry: --fcost)."""
+        out = C.c_double(0)
+        _check(lib().tsp_dev_multistart_allreduce_f64(self._h, float(cost), C.byref(out)))
         return out.value
 
     def bcast_tour(self, root, succ):

@@ -10,6 +10,7 @@
 #define _DEFAULT_SOURCE
 #include "tsp_host.h"
 
+#include <fcntl.h>
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
@@ -37,7 +38,7 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 static tsp_dev_ctx *g_ctx = NULL;
 static tsp_dev_comm *g_comm = NULL;   /* one process per GPU: this process's rank of the RCCL communicator */
 /* CLI extensions of this build (-starts, -gpus): instance_params is the reference's struct and takes no new fields */
-static int g_cli_starts = 256, g_cli_gpus = 0;
+static int g_cli_starts = -1 /* default: 256 GRASP starts / 128 individuals */, g_cli_gpus = 0;
 static cache_slot g_cache[CACHE_SLOTS];
 /* The device-side stamp array alg_2opt_tabu works on, kept from call to call (one per device instance: 4 n (n-1) / 2 bytes of
  * HBM are not allocated and freed per call).  It holds no host state: every call uploads the caller's skip_edge array and
@@ -51,7 +52,7 @@ static void tabu_cache_drop(void) {
 }
 
 static unsigned long g_clock = 0;
-static __thread long long t_sweeps, t_evals, t_moves;
+static __thread long long t_sweeps, t_evals, t_moves, t_grasp_iter_starts;
 static __thread double t_device_ms;
 
 static void dev_fail(const char *what, int rc) {
@@ -59,16 +60,24 @@ static void dev_fail(const char *what, int rc) {
           tsp_dev_last_error());
 }
 
-static tsp_dev_ctx *ctx_locked(void) {
+/* *rc_out == NULL: a failure ends the process (LOG_E, the reference's convention); else it is returned (a rank that is about
+ * to enter a collective must not exit before it: see the failure agreement of the multi-GPU section) */
+static tsp_dev_ctx *ctx_try_locked(int *rc_out) {
     if (!g_ctx) {
         const char *d = getenv("TSP_DEVICE");
         if (!d || !*d) d = getenv("LOCAL_RANK");   /* one process per GPU under torchrun / mpirun style launchers */
         int rc = tsp_dev_open(d ? atoi(d) : 0, &g_ctx);
-        if (rc) dev_fail("tsp_dev_open", rc);
+        if (rc) {
+            g_ctx = NULL;
+            if (!rc_out) dev_fail("tsp_dev_open", rc);
+            *rc_out = rc;
+            return NULL;
+        }
         atexit(tsp_host_shutdown);
     }
     return g_ctx;
 }
+
 
 static double nodes_checksum(const point *p, int n) {
     double s = 0.0;
@@ -77,7 +86,7 @@ static double nodes_checksum(const point *p, int n) {
 }
 
 /* Device copy of inst->nodes (uploaded on first use, then reused while the host array is unchanged). */
-static tsp_dev_inst *dev_inst_locked(instance *inst) {
+static tsp_dev_inst *dev_inst_try_locked(instance *inst, int *rc_out) {
     if (!inst->nodes || inst->num_nodes < 3) LOG_E("instance has no nodes (or fewer than 3)");
     const double sum = nodes_checksum(inst->nodes, inst->num_nodes);
     const int ic = inst->params.integer_cost ? 1 : 0;
@@ -95,13 +104,21 @@ static tsp_dev_inst *dev_inst_locked(instance *inst) {
     if (c->dev && g_tabu_cache.dev == c->dev) tabu_cache_drop();
     if (c->dev) tsp_dev_inst_destroy(c->dev);
     memset(c, 0, sizeof *c);
-    int rc = tsp_dev_inst_create(ctx_locked(), (const double *)inst->nodes, inst->num_nodes, (int)inst->weight_type, ic,
-                                 &c->dev);
-    if (rc) dev_fail("tsp_dev_inst_create", rc);
+    tsp_dev_ctx *ctx = ctx_try_locked(rc_out);
+    if (!ctx) return NULL;
+    int rc = tsp_dev_inst_create(ctx, (const double *)inst->nodes, inst->num_nodes, (int)inst->weight_type, ic, &c->dev);
+    if (rc) {
+        c->dev = NULL;
+        if (!rc_out) dev_fail("tsp_dev_inst_create", rc);
+        *rc_out = rc;
+        return NULL;
+    }
     c->nodes = inst->nodes; c->n = inst->num_nodes; c->wtype = (int)inst->weight_type; c->integer_cost = ic;
     c->checksum = sum; c->stamp = ++g_clock;
     return c->dev;
 }
+
+static tsp_dev_inst *dev_inst_locked(instance *inst) { return dev_inst_try_locked(inst, NULL); }
 
 void tsp_host_shutdown(void) {
     pthread_mutex_lock(&g_lock);
@@ -112,6 +129,8 @@ void tsp_host_shutdown(void) {
     if (g_ctx) { tsp_dev_close(g_ctx); g_ctx = NULL; }
     pthread_mutex_unlock(&g_lock);
 }
+
+long long tsp_host_last_grasp_iter_starts(void) { return t_grasp_iter_starts; }
 
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms) {
     if (sweeps) *sweeps = t_sweeps;
@@ -276,6 +295,7 @@ int HEU_Grasp_iter(instance *inst, int time_lim) {
     double *obj = malloc(sizeof(double) * B);
     double best = DBL_MAX;
     edge *best_edges = calloc((size_t)n, sizeof(edge));
+    t_grasp_iter_starts = 0;
     for (;;) {
         for (int b = 0; b < B; b++) {
             starts[b] = (int)(URAND() * (n - 1));
@@ -292,6 +312,7 @@ int HEU_Grasp_iter(instance *inst, int time_lim) {
                 best = obj[b];
                 for (int v = 0; v < n; v++) { best_edges[v].i = v; best_edges[v].j = succ[(size_t)b * n + v]; }
             }
+        t_grasp_iter_starts += B;
     }
     inst->solution.obj_best = best;
     memcpy(inst->solution.edges, best_edges, sizeof(edge) * (size_t)n);
@@ -645,8 +666,34 @@ static void ga_choose_survivors(int n, ga_member *pop, int pop_size, const ga_me
     free(total); free(taken);
 }
 
+/* Mutation method 3 for a batch of offspring on several devices: the offspring are independent (each is alg_2opt on a private
+ * copy, genetic.c:426-443), so GPU g takes a contiguous block of them; one thread per GPU and generation, the context and the
+ * device instance of a GPU live for the whole run. */
+typedef struct { int dev, n, count; instance *inst; tsp_dev_ctx *ctx; tsp_dev_inst *dinst; int *succ; double *obj; int rc; } ga_gpu;
+
+static void *ga_gpu_run(void *arg) {
+    ga_gpu *g = arg;
+    g->rc = 0;
+    if (!g->ctx) g->rc = tsp_dev_open(g->dev, &g->ctx);
+    if (!g->rc && !g->dinst) g->rc = tsp_dev_inst_create(g->ctx, (const double *)g->inst->nodes, g->n, (int)g->inst->weight_type,
+                                                         g->inst->params.integer_cost ? 1 : 0, &g->dinst);
+    if (!g->rc && g->count > 0) g->rc = tsp_dev_two_opt(g->dinst, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, g->count, g->succ, 1, g->n, g->obj, 2.0 /* :432 */, NULL);
+    return NULL;
+}
+
+static void ga_two_opt_over_gpus(ga_gpu *pool, int gpus, int n, int n2, int *succ, double *obj) {
+    pthread_t th[64];
+    for (int g = 0; g < gpus; g++) {
+        const int lo = (int)((long long)n2 * g / gpus), hi = (int)((long long)n2 * (g + 1) / gpus);
+        pool[g].count = hi - lo; pool[g].succ = succ + (size_t)lo * n; pool[g].obj = obj + lo;
+        if (pthread_create(&th[g], NULL, ga_gpu_run, &pool[g])) LOG_E("pthread_create failed");
+    }
+    for (int g = 0; g < gpus; g++) pthread_join(th[g], NULL);
+    for (int g = 0; g < gpus; g++) if (pool[g].rc < 0) dev_fail("tsp_dev_two_opt (GA mutation, one of the GPUs)", pool[g].rc);
+}
+
 /* :448-565 with a cap on the number of generations in addition to the time limit */
-int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_opt_prob) {
+int tsp_host_genetic_gpus(instance *inst, long long max_generations, double two_opt_prob, int gpus) {
     const int n = inst->num_nodes;
     struct timeval t0, t1;
     gettimeofday(&t0, 0);
@@ -680,6 +727,9 @@ int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_op
     char *seen = malloc((size_t)n);
     double incumbent = DBL_MAX;
     int status = 0;
+    if (gpus > 64 || (gpus > 0 && tsp_dev_count() < gpus)) LOG_E("HEU_Genetic: %d GPUs asked for, %d visible", gpus, tsp_dev_count());
+    ga_gpu *pool = gpus > 0 ? calloc((size_t)gpus, sizeof(ga_gpu)) : NULL;
+    for (int g = 0; g < gpus; g++) { pool[g].dev = g; pool[g].n = n; pool[g].inst = inst; }
     for (long long gen = 0; max_generations < 0 || gen < max_generations; gen++) {
         gettimeofday(&t1, 0);
         if (get_elapsed_time(t0, t1) > time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
@@ -709,11 +759,14 @@ int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_op
                 for (int q = 0; q < n; q++) sp[g[q]] = g[q + 1 == n ? 0 : q + 1];     /* from_chromosome_to_edges :33-42 */
                 two_opt_obj[m] = inst->solution.obj_best;                              /* copy_instance keeps obj_best; alg_2opt adds deltas to it */
             }
-            pthread_mutex_lock(&g_lock);
-            int rc = tsp_dev_two_opt(dev_inst_locked(inst), TSP_2OPT_FIRST, TSP_ENGINE_AUTO, n2, two_opt_succ, 1, n, two_opt_obj,
-                                     2.0 /* :432 */, NULL);
-            pthread_mutex_unlock(&g_lock);
-            if (rc < 0) dev_fail("tsp_dev_two_opt (GA mutation)", rc);
+            if (gpus > 0) ga_two_opt_over_gpus(pool, gpus, n, n2, two_opt_succ, two_opt_obj);
+            else {
+                pthread_mutex_lock(&g_lock);
+                int rc = tsp_dev_two_opt(dev_inst_locked(inst), TSP_2OPT_FIRST, TSP_ENGINE_AUTO, n2, two_opt_succ, 1, n, two_opt_obj,
+                                         2.0 /* :432 */, NULL);
+                pthread_mutex_unlock(&g_lock);
+                if (rc < 0) dev_fail("tsp_dev_two_opt (GA mutation)", rc);
+            }
             for (int m = 0; m < n2; m++) {                                             /* :436-441: the walk from node 0 */
                 int *g = kids[two_opt_kids[m]].genes;
                 const int *sp = two_opt_succ + (size_t)m * n;
@@ -724,9 +777,17 @@ int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_op
     }
     free(pop_slab); free(kid_slab); free(pop); free(kids); free(fit); free(parents); free(seen);
     free(two_opt_kids); free(two_opt_succ); free(two_opt_obj);
+    for (int g = 0; g < gpus; g++) {
+        if (pool[g].dinst) tsp_dev_inst_destroy(pool[g].dinst);
+        if (pool[g].ctx) tsp_dev_close(pool[g].ctx);
+    }
+    free(pool);
     return status;
 }
 
+int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_opt_prob) {
+    return tsp_host_genetic_gpus(inst, max_generations, two_opt_prob, g_cli_gpus > 1 ? g_cli_gpus : 0);   /* -gpus G of the CLI */
+}
 int tsp_host_genetic(instance *inst, long long max_generations) { return tsp_host_genetic_ex(inst, max_generations, GA_TWO_OPT_MUT); }
 int HEU_Genetic(instance *inst) { return tsp_host_genetic(inst, -1); }
 
@@ -742,162 +803,389 @@ int fitness_batch(instance *inst, const int *chromosomes, int count, double *fit
 /* ---- multi-start across GPUs ----------------------------------------------------------------------
  * Generalises HEU_Grasp_iter's loop (heuristics.c:510-544: random start :519, grasp(), keep the strictly better one :534):
  * every start is refined by alg_2opt, start k runs on rank k % world, and the ranks agree on the winner with ONE RCCL
- * all-reduce(min) of (true cost << 24 | k) and ONE broadcast of its successor list (tsp_dev_multistart_* of the C ABI). */
+ * all-reduce(min) of (true cost << 24 | k) and ONE broadcast of its successor list (tsp_dev_multistart_* of the C ABI).
+ * The same skeleton serves the population job of BASELINE configs[4]: random individuals (genetic.c:349-364), individual k
+ * on rank k % world, alg_2opt on each (the mutation-3 path, genetic.c:426-443).
+ *
+ * Failure agreement.  Between its shard and the collective a rank never exits: whatever went wrong on it (no device, a HIP
+ * error in the shard, a cost the packed word cannot carry) is CONTRIBUTED to the reduction as a value that wins the minimum
+ * (EPI_FAIL / -inf), so every rank learns of it in the same collective and every rank returns the same negative code --
+ * nobody is left waiting inside ncclAllReduce for a peer that has gone.  Only then do the callers LOG_E. */
 
-/* the libc stream of `starts` GRASP starts in the reference's draw order; keeps the draws of the starts k % world == rank */
-static int draw_shard(int n, int starts, int rank, int world, int **node_out, int **gid_out, double **u_out) {
-    int mine = 0;
-    for (int k = 0; k < starts; k++) mine += (k % world == rank);
-    int *node = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
-    int *gid = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
-    double *u = malloc(sizeof(double) * (size_t)(mine ? mine : 1) * n);
-    if (!node || !gid || !u) LOG_E("multistart: out of memory");
+enum { SHARD_GRASP = 0, SHARD_POPULATION = 1 };
+#define NO_RESULT_PACKED ((int64_t)1 << 62)
+#define EPI_FAIL ((int64_t)-1)          /* = multistart.PACK_ERROR of the Python launcher: smaller than every packed value */
+
+static int shard_count(int total, int rank, int world) { return total > rank ? (total - rank + world - 1) / world : 0; }
+
+/* The libc stream of the whole job in the reference's draw order; keeps the draws of the units k % world == rank (every rank
+ * walks the whole stream so that unit k is the same everywhere).
+ *   GRASP starts: node (heuristics.c:519), then the n URAND() of grasp() (:127)      -> node[], u[] (n doubles per start)
+ *   individuals : random_generation (genetic.c:349-364): identity, then n swaps of two rand_choice(0, n) positions -> perm[] */
+static int draw_shard(int kind, int n, int total, int rank, int world, int **gid_out, int **node_out, double **u_out, int **perm_out) {
+    const int mine = shard_count(total, rank, world), cap = mine ? mine : 1;
+    int *gid = malloc(sizeof(int) * (size_t)cap), *node = NULL, *perm = NULL, *scratch = NULL;
+    double *u = NULL;
+    if (kind == SHARD_GRASP) { node = malloc(sizeof(int) * (size_t)cap); u = malloc(sizeof(double) * (size_t)cap * n); }
+    else { perm = malloc(sizeof(int) * (size_t)cap * n); scratch = malloc(sizeof(int) * (size_t)n); }
+    if (!gid || (kind == SHARD_GRASP ? (!node || !u) : (!perm || !scratch))) LOG_E("multistart: out of memory");
     int m = 0;
-    for (int k = 0; k < starts; k++) { /* every rank walks the whole stream so that start k is the same everywhere */
-        const int nd = (int)(URAND() * (n - 1));
-        if (k % world == rank) {
-            node[m] = nd; gid[m] = k;
-            for (int q = 0; q < n; q++) u[(size_t)m * n + q] = URAND();
-            m++;
+    for (int k = 0; k < total; k++) {
+        const int keep = k % world == rank;
+        if (kind == SHARD_GRASP) {
+            const int nd = (int)(URAND() * (n - 1));
+            if (keep) { node[m] = nd; for (int q = 0; q < n; q++) u[(size_t)m * n + q] = URAND(); }
+            else for (int q = 0; q < n; q++) (void)random();
         } else {
-            for (int q = 0; q < n; q++) (void)random();
+            int *g = keep ? perm + (size_t)m * n : scratch;          /* the swaps depend on nothing but the draws */
+            if (keep) for (int q = 0; q < n; q++) g[q] = q;
+            for (int q = 0; q < n; q++) {
+                const int a = rand_choice(0, n), b = rand_choice(0, n);
+                if (keep) { const int t = g[a]; g[a] = g[b]; g[b] = t; }
+            }
         }
+        if (keep) gid[m++] = k;
     }
-    *node_out = node; *gid_out = gid; *u_out = u;
+    free(scratch);
+    *gid_out = gid;
+    if (node_out) *node_out = node;
+    if (u_out) *u_out = u;
+    if (perm_out) *perm_out = perm;
     return mine;
 }
 
-/* GRASP + alg_2opt + true cost for one shard on one device instance; best (cost, global start id, tour) of the shard */
-static int refine_shard(tsp_dev_inst *d, int n, int mine, const int *node, const int *gid, const double *u, double limit,
-                        double *best_cost, int *best_k, int *best_succ) {
+/* One shard on one device instance; best (cost, global id, tour) of the shard, first strictly better unit in id order
+ * (heuristics.c:534).  GRASP: construct + alg_2opt + TRUE cost (fitness of the walk from node 0: the reported obj carries
+ * GRASP's double-counted closing edge).  Population: fitness of the individual, alg_2opt adding its deltas to it.
+ * costs_out / succ_out / stats_out (may be NULL) are indexed by the GLOBAL unit id. */
+static int refine_shard(tsp_dev_inst *d, int kind, int n, int mine, const int *gid, const int *node, const double *u, const int *perm,
+                        double limit, double *best_cost, int *best_k, int *best_succ, double *costs_out, int *succ_out,
+                        tsp_two_opt_stats *stats_out) {
     *best_cost = DBL_MAX; *best_k = -1;
     if (mine <= 0) return 0;
     int *succ = malloc(sizeof(int) * (size_t)mine * n);
-    int *perm = malloc(sizeof(int) * (size_t)mine * n);
-    double *obj = malloc(sizeof(double) * (size_t)mine), *truec = malloc(sizeof(double) * (size_t)mine);
-    if (!succ || !perm || !obj || !truec) LOG_E("multistart: out of memory");
-    int rc = tsp_dev_construct(d, TSP_CONSTRUCT_GRASP, mine, node, u, succ, 1, n, obj, NULL);
-    if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, obj, limit, NULL);
-    if (rc >= 0) {  /* true cost = fitness of the tour walked from node 0 (the reported obj carries GRASP's offset) */
-        for (int b = 0; b < mine; b++) { int v = 0; for (int q = 0; q < n; q++) { perm[(size_t)b * n + q] = v; v = succ[(size_t)b * n + v]; } }
-        int rc2 = tsp_dev_perm_cost(d, mine, perm, n, truec);
-        if (rc2) rc = rc2;
+    int *walk = malloc(sizeof(int) * (size_t)mine * n);
+    double *obj = malloc(sizeof(double) * (size_t)mine), *cost = malloc(sizeof(double) * (size_t)mine);
+    tsp_two_opt_stats *st = stats_out ? calloc((size_t)mine, sizeof *st) : NULL;
+    if (!succ || !walk || !obj || !cost || (stats_out && !st)) LOG_E("multistart: out of memory");
+    int rc;
+    if (kind == SHARD_GRASP) {
+        rc = tsp_dev_construct(d, TSP_CONSTRUCT_GRASP, mine, node, u, succ, 1, n, obj, NULL);
+        if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, obj, limit, st);
+        if (rc >= 0) {
+            for (int b = 0; b < mine; b++) { int v = 0; for (int q = 0; q < n; q++) { walk[(size_t)b * n + q] = v; v = succ[(size_t)b * n + v]; } }
+            const int rc2 = tsp_dev_perm_cost(d, mine, walk, n, cost);
+            if (rc2) rc = rc2;
+        }
+    } else {
+        for (int b = 0; b < mine; b++) {                           /* from_chromosome_to_edges, genetic.c:33-42 */
+            const int *g = perm + (size_t)b * n;
+            int *sp = succ + (size_t)b * n;
+            for (int q = 0; q < n; q++) sp[g[q]] = g[q + 1 == n ? 0 : q + 1];
+        }
+        rc = tsp_dev_perm_cost(d, mine, perm, n, cost);            /* fitness, genetic.c:51-60 */
+        if (rc >= 0) rc = tsp_dev_two_opt(d, TSP_2OPT_FIRST, TSP_ENGINE_AUTO, mine, succ, 1, n, cost, limit, st);   /* obj_best += delta */
     }
     if (rc >= 0) {
         int bm = 0;
-        for (int b = 0; b < mine; b++)
-            if (truec[b] < *best_cost) { *best_cost = truec[b]; *best_k = gid[b]; bm = b; }
+        for (int b = 0; b < mine; b++) {
+            if (cost[b] < *best_cost) { *best_cost = cost[b]; *best_k = gid[b]; bm = b; }
+            if (costs_out) costs_out[gid[b]] = cost[b];
+            if (succ_out) memcpy(succ_out + (size_t)gid[b] * n, succ + (size_t)b * n, sizeof(int) * (size_t)n);
+            if (stats_out) stats_out[gid[b]] = st[b];
+        }
         memcpy(best_succ, succ + (size_t)bm * n, sizeof(int) * (size_t)n);
     }
-    free(succ); free(perm); free(obj); free(truec);
+    free(succ); free(walk); free(obj); free(cost); free(st);
     return rc;
 }
 
-#define NO_RESULT_PACKED ((int64_t)1 << 62)
+/* ---- the collectives of the epilogue: RCCL through libtsp_hip.so, unless the caller plugged in its own ---------------- */
+static tsp_host_collectives g_coll;    /* all NULL: RCCL */
+static int g_coll_set = 0;
+
+void tsp_host_set_collectives(const tsp_host_collectives *c) {
+    pthread_mutex_lock(&g_lock);
+    if (c) { g_coll = *c; g_coll_set = 1; } else { memset(&g_coll, 0, sizeof g_coll); g_coll_set = 0; }
+    pthread_mutex_unlock(&g_lock);
+}
+
+static long long proc_start_ticks(long pid) {   /* field 22 of /proc/<pid>/stat: start time in clock ticks since boot */
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%ld/stat", pid);
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    const size_t got = fread(buf, 1, sizeof buf - 1, fp);
+    fclose(fp);
+    buf[got] = 0;
+    char *p = strrchr(buf, ')');                 /* the command name may hold blanks and brackets */
+    if (!p) return -1;
+    long long v = -1;
+    int field = 2;
+    for (char *tok = strtok(p + 1, " "); tok; tok = strtok(NULL, " "))
+        if (++field == 22) { v = atoll(tok); break; }
+    return v;
+}
+
+/* What rank 0 leaves for the other ranks of its job: the RCCL id plus who wrote it.  A reader accepts the record only while
+ * that very process (pid AND start time) is alive -- the record of a run that crashed, or of a pid that has since been
+ * reused, is stale by construction, whatever its age.  (One node: SURVEY 8(e) shards over the GPUs of one host.) */
+typedef struct { char magic[8]; char id[TSP_COMM_ID_BYTES]; long long pid, start_ticks; } id_record;
+static const char k_id_magic[8] = {'T', 'S', 'P', 'R', 'I', 'D', '0', '2'};
+
+static void id_file_path(char *path, size_t cap) {
+    const char *f = getenv("TSP_RCCL_ID_FILE"), *port = getenv("MASTER_PORT");
+    if (f && *f) snprintf(path, cap, "%s", f);
+    else snprintf(path, cap, "/tmp/tsp_rccl_id.%ld.%ld.%s", (long)getuid(), (long)getppid(), port && *port ? port : "0");
+}
+
+static int id_record_is_live(const id_record *r) {
+    return !memcmp(r->magic, k_id_magic, sizeof k_id_magic) && r->pid > 0 && proc_start_ticks((long)r->pid) == r->start_ticks &&
+           r->start_ticks >= 0;
+}
+
+static int read_id_record(const char *path, id_record *r) {
+    const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return 0;
+    const ssize_t got = read(fd, r, sizeof *r);
+    close(fd);
+    return got == (ssize_t)sizeof *r;
+}
+
+/* Diagnostics (and the CPU tests): what a rank would make of the id file at `path` (NULL: this process's default path) --
+ * 0 nothing readable there (a symlink is never followed), 1 a record whose writer is alive, 2 a stale record. */
+int tsp_host_rccl_id_file_state(const char *path) {
+    char dflt[512];
+    if (!path) { id_file_path(dflt, sizeof dflt); path = dflt; }
+    id_record r;
+    if (!read_id_record(path, &r)) return 0;
+    return id_record_is_live(&r) ? 1 : 2;
+}
+
+/* rank 0, BEFORE its shard: whatever lies at the path is either stale (removed) or belongs to a running job (refused) */
+static void id_file_claim(void) {
+    char path[512];
+    id_file_path(path, sizeof path);
+    id_record old;
+    if (read_id_record(path, &old) && id_record_is_live(&old) && old.pid != (long long)getpid())
+        LOG_E("%s belongs to a running job (pid %lld): give this job its own TSP_RCCL_ID_FILE or MASTER_PORT", path, old.pid);
+    (void)unlink(path);
+}
 
 /* One process per GPU: the communicator of this process, formed on first use from RANK / WORLD_SIZE.  Rank 0 obtains the
- * RCCL id and leaves it in a file (TSP_RCCL_ID_FILE, default /tmp/tsp_rccl_id.<launcher pid>.<MASTER_PORT>), the others
- * wait for it; the file is removed once every rank is in. */
-static tsp_dev_comm *comm_locked(int rank, int world) {
+ * RCCL id and leaves it in a file (TSP_RCCL_ID_FILE, default /tmp/tsp_rccl_id.<uid>.<launcher pid>.<MASTER_PORT>; created
+ * with O_EXCL | O_NOFOLLOW, mode 0600, then renamed into place), the others wait for a record whose writer is alive; the
+ * file is removed once every rank is in.  Returns NULL (text in *why) instead of exiting: the caller is about to enter a
+ * collective-free failure path of its own. */
+static tsp_dev_comm *comm_try_locked(int rank, int world, char *why, size_t why_cap) {
     if (g_comm) return g_comm;
+    if (!g_ctx) { snprintf(why, why_cap, "no device context"); return NULL; }
     char path[512];
-    const char *f = getenv("TSP_RCCL_ID_FILE"), *port = getenv("MASTER_PORT");
-    if (f && *f) snprintf(path, sizeof path, "%s", f);
-    else snprintf(path, sizeof path, "/tmp/tsp_rccl_id.%ld.%s", (long)getppid(), port && *port ? port : "0");
-    char id[TSP_COMM_ID_BYTES];
+    id_file_path(path, sizeof path);
+    id_record rec;
+    memset(&rec, 0, sizeof rec);
     if (rank == 0) {
-        int rc = tsp_dev_comm_unique_id(id);
-        if (rc) LOG_E("tsp_dev_comm_unique_id failed with %d %s", rc, tsp_dev_comm_last_error());
+        int rc = tsp_dev_comm_unique_id(rec.id);
+        if (rc) { snprintf(why, why_cap, "tsp_dev_comm_unique_id failed with %d %s", rc, tsp_dev_comm_last_error()); return NULL; }
+        memcpy(rec.magic, k_id_magic, sizeof k_id_magic);
+        rec.pid = (long long)getpid();
+        rec.start_ticks = proc_start_ticks((long)getpid());
         char tmp[600];
-        snprintf(tmp, sizeof tmp, "%s.tmp", path);
-        FILE *fp = fopen(tmp, "wb");
-        if (!fp || fwrite(id, 1, sizeof id, fp) != sizeof id) LOG_E("cannot write the RCCL id to %s", tmp);
-        fclose(fp);
-        if (rename(tmp, path)) LOG_E("cannot publish the RCCL id as %s", path);
+        snprintf(tmp, sizeof tmp, "%s.%ld.tmp", path, (long)getpid());
+        (void)unlink(tmp);
+        const int fd = open(tmp, O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0 || write(fd, &rec, sizeof rec) != (ssize_t)sizeof rec) { if (fd >= 0) close(fd); snprintf(why, why_cap, "cannot write the RCCL id to %.300s", tmp); return NULL; }
+        close(fd);
+        if (rename(tmp, path)) { snprintf(why, why_cap, "cannot publish the RCCL id as %.300s", path); return NULL; }
     } else {
         struct timeval t0, t1;
         gettimeofday(&t0, 0);
         for (;;) {
-            FILE *fp = fopen(path, "rb");
-            if (fp) {
-                const size_t got = fread(id, 1, sizeof id, fp);
-                fclose(fp);
-                if (got == sizeof id) break;
-            }
+            if (read_id_record(path, &rec) && id_record_is_live(&rec)) break;
             gettimeofday(&t1, 0);
-            if (get_elapsed_time(t0, t1) > 120.0) LOG_E("rank %d: no RCCL id in %s after 120 s (is rank 0 running?)", rank, path);
+            if (get_elapsed_time(t0, t1) > 120.0) { snprintf(why, why_cap, "rank %d: no live RCCL id in %.300s after 120 s (is rank 0 running?)", rank, path); return NULL; }
             struct timespec ts = {0, 20 * 1000 * 1000};
             nanosleep(&ts, NULL);
         }
     }
-    int rc = tsp_dev_comm_init_rank(ctx_locked(), world, rank, id, &g_comm);
-    if (rc) LOG_E("tsp_dev_comm_init_rank failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
-    if (rank == 0) (void)remove(path);   /* init_rank is collective: every rank has read it */
+    int rc = tsp_dev_comm_init_rank(g_ctx, world, rank, rec.id, &g_comm);
+    if (rank == 0) (void)unlink(path);   /* init_rank is collective: every rank has read it (or this rank failed and nobody should) */
+    if (rc) { snprintf(why, why_cap, "tsp_dev_comm_init_rank failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error()); g_comm = NULL; return NULL; }
     return g_comm;
 }
 
-/* One rank's share of BASELINE config 4, no communication: `starts` GRASP starts (stream order of heuristics.c:519, :127), the
- * starts k % world == rank refined by alg_2opt on this process's device, the shard's best TRUE cost / start / tour. */
-int tsp_host_multistart_shard(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+static int coll_allreduce_i64(int rank, int world, int64_t local, int64_t *out, char *why, size_t cap) {
+    if (g_coll_set) return g_coll.allreduce_min_i64(g_coll.self, local, out);
+    tsp_dev_comm *cm = comm_try_locked(rank, world, why, cap);
+    if (!cm) return TSP_DEV_E_COMM;
+    const int rc = tsp_dev_multistart_allreduce(cm, local, out);
+    if (rc) snprintf(why, cap, "all-reduce(min) failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    return rc;
+}
+static int coll_allreduce_f64(int rank, int world, double local, double *out, char *why, size_t cap) {
+    if (g_coll_set) return g_coll.allreduce_min_f64(g_coll.self, local, out);
+    tsp_dev_comm *cm = comm_try_locked(rank, world, why, cap);
+    if (!cm) return TSP_DEV_E_COMM;
+    const int rc = tsp_dev_multistart_allreduce_f64(cm, local, out);
+    if (rc) snprintf(why, cap, "all-reduce(min, double) failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    return rc;
+}
+static int coll_bcast(int rank, int world, int root, int *buf, int stride, int n, char *why, size_t cap) {
+    if (g_coll_set) return g_coll.bcast_i32(g_coll.self, root, buf, stride, n);
+    tsp_dev_comm *cm = comm_try_locked(rank, world, why, cap);
+    if (!cm) return TSP_DEV_E_COMM;
+    const int rc = tsp_dev_multistart_bcast_tour(cm, root, buf, stride, n);
+    if (rc) snprintf(why, cap, "broadcast failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    return rc;
+}
+
+static __thread char t_epilogue_error[512];
+const char *tsp_host_multistart_last_error(void) { return t_epilogue_error; }
+
+/* The epilogue, COLLECTIVE over `world` ranks: every rank passes the outcome of its shard -- shard_rc (< 0: the shard failed),
+ * *best / *best_k (best_k < 0: empty shard), the shard's best tour in inst->solution.edges -- and every rank returns with the
+ * global winner in *best / *best_k / inst->solution, or with the SAME negative code on every rank:
+ *   TSP_HOST_E_PEER     some rank's shard failed or holds a cost the reduction cannot carry (this rank's text, if it was
+ *                       this rank, in tsp_host_multistart_last_error());
+ *   TSP_DEV_E_*         the transport itself failed on THIS rank (its peers leave their collective by its timeout).
+ * Integer costs (the reference's default): ONE all-reduce(min) of (cost << 24 | id), a failed rank contributes EPI_FAIL.
+ * --fcost (src/utility.c:285; `< bestobj` on doubles, heuristics.c:534): TWO reductions -- min of the double (a failed rank
+ * contributes -inf), then min of the id among the ranks that hold that cost (ties -> lowest id: the strict `<` in stream order).
+ * Then ONE broadcast of the winner's successor list from rank id % world, in place (stride 2). */
+int tsp_host_multistart_epilogue(instance *inst, int rank, int world, int shard_rc, double *best, int *best_k) {
     const int n = inst->num_nodes;
-    if (starts < 1 || world < 1 || rank < 0 || rank >= world) return -1;
-    int *node, *gid;
-    double *u;
-    const int mine = draw_shard(n, starts, rank, world, &node, &gid, &u);
-    int *best_succ = malloc(sizeof(int) * (size_t)n);
-    double best = DBL_MAX;
-    int best_k = -1;
+    char why[400] = "";
+    t_epilogue_error[0] = 0;
+    int failed = shard_rc < 0;
+    if (failed) snprintf(t_epilogue_error, sizeof t_epilogue_error, "rank %d: shard failed with %d %s", rank, shard_rc, tsp_dev_last_error());
+    int rc = 0, owner = -1;
     pthread_mutex_lock(&g_lock);
-    int rc = refine_shard(dev_inst_locked(inst), n, mine, node, gid, u, limit_of(inst), &best, &best_k, best_succ);
-    pthread_mutex_unlock(&g_lock);
-    if (rc < 0) dev_fail("multistart", rc);
-    if (best_k >= 0) {
-        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = best_succ[v]; }
-        inst->solution.obj_best = best;
+    if (inst->params.integer_cost) {
+        int64_t mine = NO_RESULT_PACKED, win = 0;
+        if (failed) mine = EPI_FAIL;
+        else if (*best_k >= 0 && tsp_dev_multistart_pack(*best, *best_k, &mine)) {
+            mine = EPI_FAIL;
+            snprintf(t_epilogue_error, sizeof t_epilogue_error, "rank %d: cost %f of unit %d does not fit the packed all-reduce (cost << 24 | id)", rank, *best, *best_k);
+        }
+        rc = coll_allreduce_i64(rank, world, mine, &win, why, sizeof why);
+        if (!rc && win < 0) rc = TSP_HOST_E_PEER;
+        if (!rc) {
+            if (win == NO_RESULT_PACKED) { *best = DBL_MAX; *best_k = -1; }
+            else { *best = (double)(win >> 24); *best_k = (int)(win & 0xffffff); owner = *best_k % world; }
+        }
+    } else {
+        double mine = failed || isnan(*best) ? -INFINITY : (*best_k >= 0 ? *best : INFINITY), cmin = 0.0;
+        if (!failed && isnan(*best)) snprintf(t_epilogue_error, sizeof t_epilogue_error, "rank %d: cost of unit %d is not a number", rank, *best_k);
+        rc = coll_allreduce_f64(rank, world, mine, &cmin, why, sizeof why);
+        if (!rc && cmin == -INFINITY) rc = TSP_HOST_E_PEER;
+        if (!rc) {
+            int64_t idm = *best_k >= 0 && mine == cmin ? (int64_t)*best_k : NO_RESULT_PACKED, idw = 0;
+            rc = coll_allreduce_i64(rank, world, idm, &idw, why, sizeof why);
+            if (!rc && idw < 0) rc = TSP_HOST_E_PEER;
+            if (!rc) {
+                if (idw == NO_RESULT_PACKED) { *best = DBL_MAX; *best_k = -1; }
+                else { *best = cmin; *best_k = (int)idw; owner = *best_k % world; }
+            }
+        }
     }
+    if (!rc && owner >= 0) rc = coll_bcast(rank, world, owner, &inst->solution.edges[0].j, 2, n, why, sizeof why);
+    pthread_mutex_unlock(&g_lock);
+    if (rc && rc != TSP_HOST_E_PEER) snprintf(t_epilogue_error, sizeof t_epilogue_error, "rank %d: %s", rank, why);
+    if (rc == TSP_HOST_E_PEER && !t_epilogue_error[0])
+        snprintf(t_epilogue_error, sizeof t_epilogue_error, "rank %d: a peer reported a failed shard (or a cost the reduction cannot carry)", rank);
+    if (!rc && *best_k >= 0) { stamp_edge_sources(inst); inst->solution.obj_best = *best; }
+    return rc;
+}
+
+/* One rank's share, no communication, and no exit on a device failure: the units k % world == rank on this process's
+ * device, the shard's best in inst->solution / *best / *best_k.  < 0: the failure, for the epilogue to carry. */
+static int shard_try(instance *inst, int kind, int total, int rank, int world, double *best, int *best_k, double *costs_out,
+                     int *succ_out, tsp_two_opt_stats *stats_out) {
+    const int n = inst->num_nodes;
+    int *gid, *node = NULL, *perm = NULL;
+    double *u = NULL;
+    const int mine = draw_shard(kind, n, total, rank, world, &gid, &node, &u, &perm);   /* the stream is walked whatever happens next */
+    int *best_succ = malloc(sizeof(int) * (size_t)n);
+    if (!best_succ) LOG_E("multistart: out of memory");
+    *best = DBL_MAX; *best_k = -1;
+    pthread_mutex_lock(&g_lock);
+    int rc = 0;
+    tsp_dev_inst *d = dev_inst_try_locked(inst, &rc);
+    if (d) rc = refine_shard(d, kind, n, mine, gid, node, u, perm, limit_of(inst), best, best_k, best_succ, costs_out, succ_out, stats_out);
+    pthread_mutex_unlock(&g_lock);
+    if (rc >= 0 && *best_k >= 0) {
+        for (int v = 0; v < n; v++) { inst->solution.edges[v].i = v; inst->solution.edges[v].j = best_succ[v]; }
+        inst->solution.obj_best = *best;
+    }
+    free(gid); free(node); free(u); free(perm); free(best_succ);
+    return rc < 0 ? rc : 0;
+}
+
+static int shard_args_ok(const instance *inst, int total, int rank, int world) {
+    return inst && inst->nodes && inst->num_nodes >= 3 && total >= 1 && total < (1 << 24) && world >= 1 && rank >= 0 && rank < world;
+}
+
+int tsp_host_multistart_shard(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
+    if (!shard_args_ok(inst, starts, rank, world)) return -1;
+    double best; int best_k;
+    const int rc = shard_try(inst, SHARD_GRASP, starts, rank, world, &best, &best_k, NULL, NULL, NULL);
+    if (rc < 0) dev_fail("multistart", rc);
     if (best_true_cost) *best_true_cost = best;
     if (best_start) *best_start = best_k;
-    free(node); free(gid); free(u); free(best_succ);
+    return 0;
+}
+
+int tsp_host_population_shard(instance *inst, int individuals, int rank, int world, double *best_cost, int *best_individual,
+                              double *costs_out, int *succ_out, tsp_two_opt_stats *stats_out) {
+    if (!shard_args_ok(inst, individuals, rank, world)) return -1;
+    double best; int best_k;
+    const int rc = shard_try(inst, SHARD_POPULATION, individuals, rank, world, &best, &best_k, costs_out, succ_out, stats_out);
+    if (rc < 0) dev_fail("population", rc);
+    if (best_cost) *best_cost = best;
+    if (best_individual) *best_individual = best_k;
+    return 0;
+}
+
+/* shard + (world > 1, or TSP_FORCE_COMM=1 for the tests) the collective epilogue; exits -- on EVERY rank -- only after the
+ * ranks have agreed that something failed */
+static int sharded_job(instance *inst, int kind, int total, int rank, int world, double *best_out, int *best_k_out, double *costs_out,
+                       int *succ_out, tsp_two_opt_stats *stats_out) {
+    if (!shard_args_ok(inst, total, rank, world)) return -1;
+    const char *force = getenv("TSP_FORCE_COMM");   /* tests: run the collectives with a single rank too */
+    const int collective = world > 1 || (force && *force == '1');
+    if (collective && rank == 0 && !g_coll_set) id_file_claim();   /* before the shard: the peers look for the id after theirs */
+    double best; int best_k;
+    int rc = shard_try(inst, kind, total, rank, world, &best, &best_k, costs_out, succ_out, stats_out);
+    if (collective) {
+        rc = tsp_host_multistart_epilogue(inst, rank, world, rc, &best, &best_k);
+        if (rc) LOG_E("multi-GPU %s: the ranks agreed to fail (%d): %s", kind == SHARD_GRASP ? "multi-start" : "population", rc, t_epilogue_error);
+    } else if (rc < 0) dev_fail(kind == SHARD_GRASP ? "multistart" : "population", rc);
+    if (best_out) *best_out = best;
+    if (best_k_out) *best_k_out = best_k;
     return 0;
 }
 
 /* BASELINE config 4 end to end.  world == 1: this process refines every start.  world > 1 (one process per GPU, COLLECTIVE:
- * every rank must call it): this rank refines its shard on its device, then the ranks run the all-reduce(min) of
- * (true cost << 24 | start) + the broadcast of the winner's tour over RCCL, so that EVERY rank returns the global winner in
- * inst->solution, *best_true_cost and *best_start. */
+ * every rank must call it): this rank refines its shard on its device, then the ranks run the epilogue above, so that EVERY
+ * rank returns the global winner in inst->solution, *best_true_cost and *best_start. */
 int HEU_2opt_grasp_multistart(instance *inst, int starts, int rank, int world, double *best_true_cost, int *best_start) {
-    const int n = inst->num_nodes;
-    double best = DBL_MAX;
-    int best_k = -1;
-    int rc = tsp_host_multistart_shard(inst, starts, rank, world, &best, &best_k);
-    if (rc) return rc;
-    const char *force = getenv("TSP_FORCE_COMM");   /* tests: run the collectives with a single rank too */
-    if (world > 1 || (force && *force == '1')) {
-        int64_t mine_packed = NO_RESULT_PACKED, win = 0;
-        if (best_k >= 0 && tsp_dev_multistart_pack(best, best_k, &mine_packed))
-            LOG_E("multi-GPU multi-start needs integer costs (the all-reduce packs cost << 24 | start): got %f", best);
-        pthread_mutex_lock(&g_lock);
-        tsp_dev_comm *cm = comm_locked(rank, world);
-        rc = tsp_dev_multistart_allreduce(cm, mine_packed, &win);
-        if (!rc && win != NO_RESULT_PACKED) {
-            best = (double)(win >> 24); best_k = (int)(win & 0xffffff);
-            rc = tsp_dev_multistart_bcast_tour(cm, best_k % world, &inst->solution.edges[0].j, 2, n);   /* in place, stride 2 */
-        }
-        pthread_mutex_unlock(&g_lock);
-        if (rc) LOG_E("multi-start collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
-        if (best_k >= 0) { stamp_edge_sources(inst); inst->solution.obj_best = best; }
-    }
-    if (best_true_cost) *best_true_cost = best;
-    if (best_start) *best_start = best_k;
-    return 0;
+    return sharded_job(inst, SHARD_GRASP, starts, rank, world, best_true_cost, best_start, NULL, NULL, NULL);
 }
 
-/* The same job in ONE process on `gpus` devices (0 .. gpus-1): one thread, context and device instance per GPU, shard
- * k % gpus on GPU k, then ncclCommInitAll + the grouped all-reduce(min) + broadcast.  The libc stream is drawn once,
+/* BASELINE config 5 end to end: `individuals` random individuals (genetic.c:349-364, libc stream), individual k on rank
+ * k % world, alg_2opt on each (genetic.c:426-443 without its 2 s limit), the best refined individual on every rank. */
+int HEU_2opt_population_multistart(instance *inst, int individuals, int rank, int world, double *best_cost, int *best_individual,
+                                   double *costs_out, int *succ_out, tsp_two_opt_stats *stats_out) {
+    return sharded_job(inst, SHARD_POPULATION, individuals, rank, world, best_cost, best_individual, costs_out, succ_out, stats_out);
+}
+
+/* The same jobs in ONE process on `gpus` devices (0 .. gpus-1): one thread, context and device instance per GPU, shard
+ * k % gpus on GPU k, then ncclCommInitAll + the grouped reductions + broadcast.  The libc stream is drawn once,
  * up front, by the calling thread (random() is process-global, heuristics.c:519). */
 typedef struct {
-    instance *inst; int dev, mine; const int *node, *gid; const double *u; double limit;
+    instance *inst; int kind, dev, rank, world, total, mine; int *gid, *node, *perm; double *u; double limit;
     tsp_dev_ctx *ctx; tsp_dev_inst *dinst; double best; int best_k; int *best_succ; int rc; double seconds;
+    double *costs_out; int *succ_out; tsp_two_opt_stats *stats_out;
 } gpu_job;
 
 static void *gpu_job_run(void *arg) {
@@ -908,59 +1196,77 @@ static void *gpu_job_run(void *arg) {
     j->rc = tsp_dev_open(j->dev, &j->ctx);
     if (!j->rc) j->rc = tsp_dev_inst_create(j->ctx, (const double *)j->inst->nodes, n, (int)j->inst->weight_type,
                                             j->inst->params.integer_cost ? 1 : 0, &j->dinst);
-    if (!j->rc) j->rc = refine_shard(j->dinst, n, j->mine, j->node, j->gid, j->u, j->limit, &j->best, &j->best_k, j->best_succ);
+    if (!j->rc) j->rc = refine_shard(j->dinst, j->kind, n, j->mine, j->gid, j->node, j->u, j->perm, j->limit, &j->best, &j->best_k,
+                                     j->best_succ, j->costs_out, j->succ_out, j->stats_out);
     gettimeofday(&t1, 0);
     j->seconds = get_elapsed_time(t0, t1);
     return NULL;
 }
 
-int tsp_host_multistart_gpus(instance *inst, int starts, int gpus, double *best_true_cost, int *best_start, double *shard_seconds) {
+static int job_over_gpus(instance *inst, int kind, int total, int gpus, double *best_out, int *best_k_out, double *shard_seconds,
+                         double *costs_out, int *succ_out, tsp_two_opt_stats *stats_out) {
     const int n = inst->num_nodes;
-    if (starts < 1 || gpus < 1 || gpus > 64) return -1;
-    if (tsp_dev_count() < gpus) LOG_E("tsp_host_multistart_gpus: %d GPUs asked for, %d visible", gpus, tsp_dev_count());
+    if (!shard_args_ok(inst, total, 0, 1) || gpus < 1 || gpus > 64) return -1;
+    if (tsp_dev_count() < gpus) LOG_E("%d GPUs asked for, %d visible", gpus, tsp_dev_count());
     gpu_job *jobs = calloc((size_t)gpus, sizeof(gpu_job));
-    int **nodes = calloc((size_t)gpus, sizeof(int *)), **gids = calloc((size_t)gpus, sizeof(int *));
-    double **us = calloc((size_t)gpus, sizeof(double *));
-    /* one pass over the stream per GPU would draw it `gpus` times: draw once, deal the starts out */
+    /* one pass over the stream per GPU would draw it `gpus` times: draw the whole job once and deal the units out */
+    int *gid_all, *node_all = NULL, *perm_all = NULL;
+    double *u_all = NULL;
+    (void)draw_shard(kind, n, total, 0, 1, &gid_all, &node_all, &u_all, &perm_all);
     for (int g = 0; g < gpus; g++) {
-        int mine = 0;
-        for (int k = 0; k < starts; k++) mine += (k % gpus == g);
-        nodes[g] = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
-        gids[g] = malloc(sizeof(int) * (size_t)(mine ? mine : 1));
-        us[g] = malloc(sizeof(double) * (size_t)(mine ? mine : 1) * n);
-        jobs[g].mine = 0;
+        gpu_job *j = &jobs[g];
+        j->mine = shard_count(total, g, gpus);
+        const int cap = j->mine ? j->mine : 1;
+        j->gid = malloc(sizeof(int) * (size_t)cap);
+        if (kind == SHARD_GRASP) { j->node = malloc(sizeof(int) * (size_t)cap); j->u = malloc(sizeof(double) * (size_t)cap * n); }
+        else j->perm = malloc(sizeof(int) * (size_t)cap * n);
+        for (int m = 0; m < j->mine; m++) {
+            const int k = g + m * gpus;
+            j->gid[m] = k;
+            if (kind == SHARD_GRASP) { j->node[m] = node_all[k]; memcpy(j->u + (size_t)m * n, u_all + (size_t)k * n, sizeof(double) * (size_t)n); }
+            else memcpy(j->perm + (size_t)m * n, perm_all + (size_t)k * n, sizeof(int) * (size_t)n);
+        }
     }
-    for (int k = 0; k < starts; k++) {
-        const int g = k % gpus, m = jobs[g].mine++;
-        nodes[g][m] = (int)(URAND() * (n - 1)); gids[g][m] = k;
-        for (int q = 0; q < n; q++) us[g][(size_t)m * n + q] = URAND();
-    }
+    free(gid_all); free(node_all); free(u_all); free(perm_all);
     pthread_t *th = calloc((size_t)gpus, sizeof(pthread_t));
     for (int g = 0; g < gpus; g++) {
-        jobs[g].inst = inst; jobs[g].dev = g; jobs[g].node = nodes[g]; jobs[g].gid = gids[g]; jobs[g].u = us[g];
-        jobs[g].limit = limit_of(inst); jobs[g].best_succ = malloc(sizeof(int) * (size_t)n);
-        if (pthread_create(&th[g], NULL, gpu_job_run, &jobs[g])) LOG_E("pthread_create failed");
+        gpu_job *j = &jobs[g];
+        j->inst = inst; j->kind = kind; j->dev = g; j->rank = g; j->world = gpus; j->total = total; j->limit = limit_of(inst);
+        j->best = DBL_MAX; j->best_k = -1; j->best_succ = malloc(sizeof(int) * (size_t)n);
+        j->costs_out = costs_out; j->succ_out = succ_out; j->stats_out = stats_out;
+        if (pthread_create(&th[g], NULL, gpu_job_run, j)) LOG_E("pthread_create failed");
     }
     for (int g = 0; g < gpus; g++) pthread_join(th[g], NULL);
+    /* one process: a failed shard is known to this thread, nobody is inside a collective yet */
     for (int g = 0; g < gpus; g++)
-        if (jobs[g].rc < 0) dev_fail("tsp_host_multistart_gpus: shard", jobs[g].rc);
-    /* the epilogue: all-reduce(min) of the packed bests, broadcast of the winner's tour from its owner, over RCCL */
+        if (jobs[g].rc < 0) dev_fail("shard on one of the GPUs", jobs[g].rc);
+    /* the epilogue: the reductions and the broadcast of the winner's tour from its owner, over RCCL, grouped */
     tsp_dev_ctx **ctxs = calloc((size_t)gpus, sizeof(tsp_dev_ctx *));
     tsp_dev_comm **comms = calloc((size_t)gpus, sizeof(tsp_dev_comm *));
     int64_t *loc = calloc((size_t)gpus, sizeof(int64_t)), *win = calloc((size_t)gpus, sizeof(int64_t));
-    for (int g = 0; g < gpus; g++) {
-        ctxs[g] = jobs[g].ctx;
-        loc[g] = NO_RESULT_PACKED;
-        if (jobs[g].best_k >= 0 && tsp_dev_multistart_pack(jobs[g].best, jobs[g].best_k, &loc[g]))
-            LOG_E("multi-GPU multi-start needs integer costs (the all-reduce packs cost << 24 | start): got %f", jobs[g].best);
-    }
+    double *cloc = calloc((size_t)gpus, sizeof(double)), *cwin = calloc((size_t)gpus, sizeof(double));
+    for (int g = 0; g < gpus; g++) ctxs[g] = jobs[g].ctx;
     int rc = tsp_dev_comm_init_all(ctxs, gpus, comms);
-    if (!rc) rc = tsp_dev_multistart_allreduce_group(comms, gpus, loc, win);
-    for (int g = 1; g < gpus && !rc; g++) if (win[g] != win[0]) rc = TSP_DEV_E_COMM;   /* every rank must hold the same minimum */
     double best = DBL_MAX;
     int best_k = -1;
-    if (!rc && win[0] != NO_RESULT_PACKED) {
-        best = (double)(win[0] >> 24); best_k = (int)(win[0] & 0xffffff);
+    if (!rc && inst->params.integer_cost) {
+        for (int g = 0; g < gpus; g++) {
+            loc[g] = NO_RESULT_PACKED;
+            if (jobs[g].best_k >= 0 && tsp_dev_multistart_pack(jobs[g].best, jobs[g].best_k, &loc[g]))
+                LOG_E("cost %f of unit %d does not fit the packed all-reduce (cost << 24 | id)", jobs[g].best, jobs[g].best_k);
+        }
+        rc = tsp_dev_multistart_allreduce_group(comms, gpus, loc, win);
+        for (int g = 1; g < gpus && !rc; g++) if (win[g] != win[0]) rc = TSP_DEV_E_COMM;   /* every rank must hold the same minimum */
+        if (!rc && win[0] != NO_RESULT_PACKED) { best = (double)(win[0] >> 24); best_k = (int)(win[0] & 0xffffff); }
+    } else if (!rc) {
+        for (int g = 0; g < gpus; g++) cloc[g] = jobs[g].best_k >= 0 ? jobs[g].best : INFINITY;
+        rc = tsp_dev_multistart_allreduce_f64_group(comms, gpus, cloc, cwin);
+        for (int g = 0; g < gpus && !rc; g++) loc[g] = jobs[g].best_k >= 0 && jobs[g].best == cwin[g] ? (int64_t)jobs[g].best_k : NO_RESULT_PACKED;
+        if (!rc) rc = tsp_dev_multistart_allreduce_group(comms, gpus, loc, win);
+        for (int g = 1; g < gpus && !rc; g++) if (win[g] != win[0] || cwin[g] != cwin[0]) rc = TSP_DEV_E_COMM;
+        if (!rc && win[0] != NO_RESULT_PACKED) { best = cwin[0]; best_k = (int)win[0]; }
+    }
+    if (!rc && best_k >= 0) {
         const int owner = best_k % gpus;
         int *tour = malloc(sizeof(int) * (size_t)n);
         rc = tsp_dev_multistart_bcast_tour_group(comms, gpus, owner, jobs[owner].best_succ, 1, n, (owner + 1) % gpus, tour);
@@ -968,18 +1274,27 @@ int tsp_host_multistart_gpus(instance *inst, int starts, int gpus, double *best_
         free(tour);
         inst->solution.obj_best = best;
     }
-    if (rc) LOG_E("multi-start collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
-    if (best_true_cost) *best_true_cost = best;
-    if (best_start) *best_start = best_k;
+    if (rc) LOG_E("multi-GPU collective failed with %d %s %s", rc, tsp_dev_comm_last_error(), tsp_dev_last_error());
+    if (best_out) *best_out = best;
+    if (best_k_out) *best_k_out = best_k;
     for (int g = 0; g < gpus; g++) {
         if (shard_seconds) shard_seconds[g] = jobs[g].seconds;
         tsp_dev_comm_destroy(comms[g]);
         if (jobs[g].dinst) tsp_dev_inst_destroy(jobs[g].dinst);
         if (jobs[g].ctx) tsp_dev_close(jobs[g].ctx);
-        free(nodes[g]); free(gids[g]); free(us[g]); free(jobs[g].best_succ);
+        free(jobs[g].gid); free(jobs[g].node); free(jobs[g].u); free(jobs[g].perm); free(jobs[g].best_succ);
     }
-    free(jobs); free(nodes); free(gids); free(us); free(th); free(ctxs); free(comms); free(loc); free(win);
+    free(jobs); free(th); free(ctxs); free(comms); free(loc); free(win); free(cloc); free(cwin);
     return 0;
+}
+
+int tsp_host_multistart_gpus(instance *inst, int starts, int gpus, double *best_true_cost, int *best_start, double *shard_seconds) {
+    return job_over_gpus(inst, SHARD_GRASP, starts, gpus, best_true_cost, best_start, shard_seconds, NULL, NULL, NULL);
+}
+
+int tsp_host_population_gpus(instance *inst, int individuals, int gpus, double *best_cost, int *best_individual, double *shard_seconds,
+                             double *costs_out, int *succ_out, tsp_two_opt_stats *stats_out) {
+    return job_over_gpus(inst, SHARD_POPULATION, individuals, gpus, best_cost, best_individual, shard_seconds, costs_out, succ_out, stats_out);
 }
 
 /* ---- src/solver.c:262-299 ------------------------------------------------------------------------------- */
@@ -1008,9 +1323,18 @@ int TSP_heuc(instance *inst) {
         /* one process, -gpus G devices: threads + ncclCommInitAll; one process per GPU (RANK / WORLD_SIZE in the
          * environment, as torchrun / mpirun set them): ncclCommInitRank, device LOCAL_RANK; else this process alone */
         double cost = 0.0; int start = -1;
-        if (g_cli_gpus >= 1 && world_env == 1) tsp_host_multistart_gpus(inst, g_cli_starts, g_cli_gpus, &cost, &start, NULL);
-        else HEU_2opt_grasp_multistart(inst, g_cli_starts, rank_env, world_env, &cost, &start);
-        if (inst->params.verbose >= 1 && !inst->params.perf_prof && rank_env == 0) LOG_I("best start %d of %d, true cost %0.0f", start, g_cli_starts, cost);
+        const int starts = g_cli_starts > 0 ? g_cli_starts : 256;
+        if (g_cli_gpus >= 1 && world_env == 1) tsp_host_multistart_gpus(inst, starts, g_cli_gpus, &cost, &start, NULL);
+        else HEU_2opt_grasp_multistart(inst, starts, rank_env, world_env, &cost, &start);
+        if (inst->params.verbose >= 1 && !inst->params.perf_prof && rank_env == 0) LOG_I("best start %d of %d, true cost %f", start, starts, cost);
+        break;
+    }
+    case SOLVE_2OPT_POP_MULTI: {   /* BASELINE configs[4]; the same three ways */
+        double cost = 0.0; int who = -1;
+        const int individuals = g_cli_starts > 0 ? g_cli_starts : 128;
+        if (g_cli_gpus >= 1 && world_env == 1) tsp_host_population_gpus(inst, individuals, g_cli_gpus, &cost, &who, NULL, NULL, NULL, NULL);
+        else HEU_2opt_population_multistart(inst, individuals, rank_env, world_env, &cost, &who, NULL, NULL, NULL);
+        if (inst->params.verbose >= 1 && !inst->params.perf_prof && rank_env == 0) LOG_I("best individual %d of %d, cost %f", who, individuals, cost);
         break;
     }
     case SOLVE_TABU_STEP:
@@ -1021,7 +1345,7 @@ int TSP_heuc(instance *inst) {
         break;
     default:
         LOG_E("method %s is outside this build's scope (2-opt hot path: GREEDY, GREEDY_ITER, EXTR_MILE, GRASP, GRASP_ITER, 2OPT_EXTR_MIL, "
-              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GRASP_MULTI, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND, GENETIC)",
+              "2OPT_GRASP, 2OPT_GRASP_ITER, 2OPT_GRASP_MULTI, 2OPT_POP_MULTI, 2OPT_GREEDY, 2OPT_GREEDY_ITER, VNS, TABU_STEP, TABU_LIN, TABU_RAND, GENETIC)",
               inst->params.method.name ? inst->params.method.name : "?");
     }
     gettimeofday(&t1, 0);
@@ -1047,6 +1371,7 @@ static const struct { const char *prefix; int len; solver_type id; const char *n
     {"2OPT_GRASP", 9, SOLVE_2OPT_GRASP, "2-OPT HEURISTIC WITH GRASP INITIALIZATION"},
     {"2OPT_GRASP_ITER", 15, SOLVE_2OPT_GRASP_ITER, "2-OPT HEURISTIC WITH ITERATIVE GRASP INITIALIZATION"},
     {"2OPT_GRASP_MULTI", 16, SOLVE_2OPT_GRASP_MULTI, "GRASP MULTI-START, 2-OPT ON EVERY START, SHARDED OVER THE GPUS (extension)"},
+    {"2OPT_POP_MULTI", 14, SOLVE_2OPT_POP_MULTI, "RANDOM POPULATION, 2-OPT ON EVERY INDIVIDUAL, SHARDED OVER THE GPUS (extension)"},
     {"2OPT_GREEDY", 11, SOLVE_2OPT_GREEDY, "2-OPT HEURISTIC WITH GREEDY INITIALIZATION"},
     {"2OPT_GREEDY_ITER", 16, SOLVE_2OPT_GREEDY_ITER, "2-OPT HEURISTIC WITH ITERATIVE GREEDY INITIALIZATION"},
     {"2OPT_EXTR_MIL", 13, SOLVE_2OPT_EXTR_MIL, "2-OPT HEURISTIC WITH EXTRA MILEAGE INITIALIZATION"},
@@ -1116,8 +1441,8 @@ void parse_comand_line(int argc, const char *argv[], instance *inst) { /* src/ut
         printf("-verbose <level>          The verbosity level of the debugging printing\n");
         printf("-method <type>            The method used to solve the problem. Use \"--methods\" to see the list of available methods\n");
         printf("-seed <seed>              The seed for random generation\n");
-        printf("-starts <S>               2OPT_GRASP_MULTI: number of GRASP starts (default 256)\n");
-        printf("-gpus <G>                 2OPT_GRASP_MULTI: GPUs of this process (or launch one process per GPU with RANK / WORLD_SIZE set)\n");
+        printf("-starts <S>               2OPT_GRASP_MULTI: number of GRASP starts (default 256); 2OPT_POP_MULTI: random individuals (default 128)\n");
+        printf("-gpus <G>                 2OPT_GRASP_MULTI / 2OPT_POP_MULTI / GENETIC: GPUs of this process (or launch one process per GPU with RANK / WORLD_SIZE set)\n");
         printf("--fcost                   Whether you want float costs in the problem\n");
         printf("--perfprof                Print only the objective (machine mode)\n");
         printf("--v, --version            Software's current version\n");

@@ -84,52 +84,103 @@ def broadcast_winner(succ, winner_start, world, device=None):
     return succ
 
 
-def run_sharded(refine, num_starts, n, rank=0, world=1, device=None, comm=None):
-    """The multi-start launcher.
+class _TorchCollectives:
+    """The launcher's three collectives over torch.distributed (backend "nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
 
-    comm: an engine.Comm (the C ABI's RCCL communicator, tsp_dev_multistart_allreduce / _bcast_tour) -- the collectives then
-    run through libtsp_hip.so exactly as the C host's HEU_2opt_grasp_multistart runs them; None: torch.distributed.
+    def __init__(self, device=None):
+        self.device = device
+
+    def allreduce_min(self, packed):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([packed], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def allreduce_min_f64(self, cost):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([cost], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def bcast_tour(self, root, tour):
+        import torch
+        import torch.distributed as dist
+        buf = torch.from_numpy(tour).to(self.device) if self.device is not None else torch.from_numpy(tour)
+        dist.broadcast(buf, src=root)
+        tour[:] = buf.cpu().numpy()
+        return tour
+
+
+class _NoCollectives:
+    """world == 1 without a communicator: the reductions of one value are that value."""
+
+    def allreduce_min(self, packed):
+        return packed
+
+    def allreduce_min_f64(self, cost):
+        return cost
+
+    def bcast_tour(self, root, tour):
+        return tour
+
+
+def run_sharded(refine, num_starts, n, rank=0, world=1, device=None, comm=None, integer_costs=True):
+    """The multi-start launcher (the Python twin of the C host's sharded_job / tsp_host_multistart_epilogue).
+
+    comm: an engine.Comm (the C ABI's RCCL communicator, tsp_dev_multistart_allreduce / _allreduce_f64 / _bcast_tour) -- the
+    collectives then run through libtsp_hip.so exactly as the C host runs them; None: torch.distributed (world > 1) or nothing.
 
     refine(ids) -> (costs, tours): for the global start ids `ids` (this rank's shard, ascending) the true tour cost of
     every refined start and the refined tours as an int32 array [len(ids), n] of successor lists.
     Returns {"cost", "start", "tour" (np.int32 [n], the winner's, on EVERY rank), "seconds" (this rank's refine time),
-    "local_starts"}.  world > 1 needs an initialised torch.distributed process group; the only collectives are one
-    all_reduce(MIN) of an int64 and one broadcast of n int32 from the winner's owner.
+    "local_starts"}.
+
+    integer_costs (the reference's default): ONE all_reduce(MIN) of the packed (cost << 24 | start) and ONE broadcast of n
+    int32 from the winner's owner.  integer_costs=False (--fcost, src/utility.c:285): TWO reductions -- MIN of the double cost,
+    then MIN of the start id among the ranks that hold it (ties -> lowest start: the strict `<` of src/heuristics.c:534 in
+    stream order) -- and the broadcast.  A rank that cannot contribute (refine raised, a cost that cannot be packed) does not
+    leave before the collective: it contributes PACK_ERROR / -inf, which wins the minimum, so that EVERY rank raises.
     """
     ids = shard_starts(num_starts, rank, world)
+    coll = comm if comm is not None else (_TorchCollectives(device) if world > 1 else _NoCollectives())
     t0 = time.perf_counter()
-    costs, tours = refine(ids)
+    failure = None
+    try:
+        costs, tours = refine(ids)
+        tours = np.ascontiguousarray(tours, dtype=np.int32).reshape(len(ids), n)
+    except Exception as e:      # noqa: BLE001 -- carried to every rank through the reduction, re-raised below
+        failure, costs, tours = e, [], np.zeros((0, n), dtype=np.int32)
     seconds = time.perf_counter() - t0
-    tours = np.ascontiguousarray(tours, dtype=np.int32).reshape(len(ids), n)
-    packed = local_best(costs, ids)
-    if comm is not None:
-        win = comm.allreduce_min(packed)
+    if integer_costs:
+        packed = PACK_ERROR if failure is not None else local_best(costs, ids)
+        win = coll.allreduce_min(packed)
         if win == PACK_ERROR:
-            raise UnpackableCost("a rank holds a cost the packed all-reduce cannot carry")   # every rank raises: no one waits
+            if failure is not None:
+                raise failure
+            raise UnpackableCost("a rank failed its shard or holds a cost the packed all-reduce cannot carry")
+        assert win != NO_RESULT
         cost, start = unpack(win)
-        tour = np.zeros(n, dtype=np.int32)
-        if owner_of(start, world) == rank:
-            tour[:] = tours[ids.index(start)]
-        comm.bcast_tour(owner_of(start, world), tour)
-    elif world > 1:
-        import torch
-        t = torch.tensor([packed], dtype=torch.int64, device=device)
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == PACK_ERROR:
-            raise UnpackableCost("a rank holds a cost the packed all-reduce cannot carry")   # every rank raises: no one waits
-        cost, start = unpack(int(t.item()))
-        buf = torch.zeros(n, dtype=torch.int32, device=device)
-        if owner_of(start, world) == rank:
-            buf.copy_(torch.from_numpy(tours[ids.index(start)]))
-        broadcast_winner(buf, start, world)
-        tour = buf.cpu().numpy()
     else:
-        if packed == PACK_ERROR:
-            raise UnpackableCost("a cost the packed reduction cannot carry")
-        assert packed != NO_RESULT
-        cost, start = unpack(packed)
-        tour = tours[ids.index(start)].copy()
+        mine, mine_k = float("inf"), NO_RESULT
+        for c, k in zip(costs, ids):
+            if c != c:
+                failure = failure or ValueError("cost of start %d is not a number" % k)
+            elif c < mine:
+                mine, mine_k = float(c), k
+        cmin = coll.allreduce_min_f64(float("-inf") if failure is not None else mine)
+        if cmin == float("-inf"):
+            if failure is not None:
+                raise failure
+            raise RuntimeError("a rank failed its shard")
+        start = coll.allreduce_min(mine_k if mine == cmin else NO_RESULT)
+        assert start != NO_RESULT
+        cost = cmin
+    tour = np.zeros(n, dtype=np.int32)
+    if owner_of(start, world) == rank:
+        tour[:] = tours[ids.index(start)]
+    coll.bcast_tour(owner_of(start, world), tour)
     return {"cost": cost, "start": start, "tour": tour, "seconds": seconds, "local_starts": len(ids)}
 
 
