@@ -26,17 +26,34 @@
 // contiguous ranges (every wave does the same number of row steps; at most two strips per wave).  Per row step a lane
 // computes D(p, q) for its RJ columns (row operands are wave-uniform: scalar loads, no LDS), forms
 //     sum = [D(p - 1, q - 1) - e[q - 1]] + D(p, q)           (the bracket: own register, or v_add_u32_dpp wave_shr:1)
-// and compares it with bd + e[p - 1]: one integer compare per pair, and a rarely taken branch that does the exact
-// bookkeeping (delta, tie-break on node ids) for the few pairs that reach a lane's best.
+// and compares it with wbd + e[p - 1], wbd = the best delta any lane of the WAVE has seen so far: a wave-uniform bound, so the
+// common path is one integer minimum per pair and one compare against a scalar per row step, and a rarely taken branch
+// does the exact bookkeeping (delta, tie-break on node ids) for the few pairs that reach that bound -- about ln(pairs of the
+// wave) times per wave.  Measured and not kept: a per-lane bound (a wave's 64 RJ pairs per row step held one that beat its
+// own lane's best almost every step: 47.7 us per sweep at RJ = 4); a bound shared by all waves through one word per tour
+// (atomicMin on improvement, re-read every 16 rows: 4 096 waves on one L2 line cost more than the pruning saves, 69.6 us).
 #pragma once
 #include "two_opt_step.hpp"
 
 #pragma clang fp contract(off)
 
+#ifndef TSP_EXH_EXP
+#define TSP_EXH_EXP 0
+#endif
+
 namespace tsp {
+
+#ifdef TSP_STAMPS
+// diagnostic build: per wave {100 MHz wall clock at start, at the end of its rows, shader cycles in between, 0}; [4] last
+// candidate published, [5] apply done in g_exh_t (tools/diag_exh.py reads them).  Plain stores to slots of their own: 4 096
+// atomics on one word at the start of a kernel would be the thing measured.
+__device__ unsigned long long g_exh_w[8192 * 4];
+__device__ unsigned long long g_exh_t[8];
+#endif
 
 constexpr int kExhPad = 1024;          // positions past n that k_move_pos fills (>= the widest strip + 2)
 constexpr int kExhCluster = 32;        // blocks per first-level arrival counter
+constexpr int kRowBatch = 4;           // rows whose operands one scalar load instruction fetches
 
 template <int WT>
 constexpr bool exh_metric() { return WT == WT_EUC_2D_ICOORD || WT == WT_CEIL_2D_ICOORD || WT == WT_ATT_ICOORD; }
@@ -91,14 +108,12 @@ __global__ __launch_bounds__(kScanThreads) void k_move_pos(const double2 *__rest
     pid[pbase + k] = u;
 }
 
-struct ExhArgs {
-    const double2 *pxy;
-    const int *pe, *pid;
-    int waves_total;       // waves of one tour's grid
-};
-
 template <int WT, bool INT, int RJ>
-__global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const ExhArgs x) {
+__global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const double2 *__restrict__ pxy_all, const int *__restrict__ pe_all,
+                                                      const int *__restrict__ pid_all, int waves_total) {
+    // the position arrays are kernel arguments of their own, restrict-qualified: the row operands are wave-uniform loads, and
+    // the compiler only issues them as scalar loads (s_load: no vector-memory slot, no VGPRs) when it can prove that the
+    // kernel's own stores and atomics (candidate slots, tickets) never touch them
     static_assert(exh_metric<WT>(), "integer-coordinate metrics only");
     constexpr int W = 64 * RJ, WEFF = W - 1;
     const int tour = blockIdx.z;
@@ -106,22 +121,27 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const Ex
     if (st->done) return;
     const int n = a.n, tid = threadIdx.x, lane = tid & 63;
     const size_t pbase = (size_t)tour * (n + kExhPad);
-    const double2 *__restrict__ pxy = x.pxy + pbase;
-    const int *__restrict__ pe = x.pe + pbase;
-    const int *__restrict__ pid = x.pid + pbase;
+    const double2 *__restrict__ pxy = pxy_all + pbase;
+    const int *__restrict__ pe = pe_all + pbase;
+    const int *__restrict__ pid = pid_all + pbase;
 
+#ifdef TSP_STAMPS
+    const unsigned long long stamp_r0 = wall_clock64(), stamp_c0 = clock64();
+    unsigned long long stamp_hits = 0, stamp_hit_cycles = 0;
+#endif
     // ---- this wave's share: units [u_lo, u_hi) of the strips' rows laid end to end --------------------------------
     const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kScanThreads / 64) + (tid >> 6));
     const int strips = (n + WEFF - 1) / WEFF;                       // pair-columns 0 .. n-1
     long long total = 0;
     for (int s = 0; s < strips; ++s) total += min(n - 1, s * WEFF + WEFF - 1);   // pair-rows p' < q' <= Q0 + WEFF - 1, p' <= n - 2
-    const long long per = (total + x.waves_total - 1) / x.waves_total;
+    const long long per = (total + waves_total - 1) / waves_total;
     long long u_lo = per * gw, u_hi = min(total, u_lo + per);
 
     int bd = -1, bp = -1, bq = -1;     // integer costs: delta < 0  <=>  delta <= -1; (bd, no pair) loses every tie
-    const int bias0 = lane == 0 ? -(1 << 30) : 0;   // lane 0's first column has no left neighbour in this wave: never a hit
+    int wbd = -1;                      // wave-uniform: the lowest delta any lane of this wave has seen
 
-    // exact bookkeeping for a pair that reached its lane's best: delta, then the reference's tie-break on node ids
+    // exact bookkeeping for a pair that reached the wave's best: delta, then -- on a tie only -- the reference's tie-break on
+    // node ids (two dependent global loads: not on the path of a strict improvement)
     auto consider = [&](int sum, int erow, int pp, int qq, bool valid) {
         const int d = sum - erow;
         if (valid && d <= bd) {
@@ -158,52 +178,90 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const Ex
         }
         // rows p = pa + 1 .. pb: D(p, .), then the pairs (p - 1, q - 1).  Up to p = Q0 every column of the strip lies above
         // the row (q_k > p for every evaluated pair); beyond it the pairs on and below the diagonal are masked.
-        auto step = [&](int p, const double2 r, const int erow, auto pred_c) {
+        auto step = [&](int p, const double2 r_in, const int erow, auto pred_c) {
             constexpr bool PRED = decltype(pred_c)::value;
             int D[RJ], sum[RJ];
+#if TSP_EXH_EXP == 1
+            double2 r;   // experiment: row operands in VGPRs
+            asm volatile("v_mov_b32 %0, %1" : "=v"(((int *)&r)[0]) : "s"(((const int *)&r_in)[0]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(((int *)&r)[1]) : "s"(((const int *)&r_in)[1]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(((int *)&r)[2]) : "s"(((const int *)&r_in)[2]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(((int *)&r)[3]) : "s"(((const int *)&r_in)[3]));
+#else
+            const double2 r = r_in;
+#endif
 #pragma unroll
             for (int k = 0; k < RJ; ++k) D[k] = exh_dist<WT>(cx[k], cy[k], r.x, r.y);
+            // lane 0's first column has no left neighbour in this wave (the DPP hands it 0): its pair belongs to the strip on
+            // the left; should D alone ever pass the test below, the bookkeeping drops it (valid == false)
             sum[0] = __builtin_amdgcn_update_dpp(0, S[RJ - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, true) + D[0];
 #pragma unroll
             for (int k = 1; k < RJ; ++k) sum[k] = S[k - 1] + D[k];
-            const int thr = bd + erow;
-            bool hit = sum[0] <= thr + bias0 && (!PRED || qk[0] > p);
+            const int thr = wbd + erow;   // scalar
+            bool hit = false;
 #pragma unroll
-            for (int k = 1; k < RJ; ++k) hit = hit || (sum[k] <= thr && (!PRED || qk[k] > p));
+            for (int k = 0; k < RJ; ++k) hit = hit || (sum[k] <= thr && (!PRED || qk[k] > p));
 #pragma unroll
             for (int k = 0; k < RJ; ++k) S[k] = D[k] - ce[k];
             if (__builtin_expect(__any(hit), 0)) {
+#ifdef TSP_STAMPS
+                const unsigned long long sc0 = clock64();
+#endif
 #pragma unroll
                 for (int k = 0; k < RJ; ++k) consider(sum[k], erow, p - 1, qk[k] - 1, (k > 0 || lane > 0) && qk[k] > p);
+                const int nb = (int)(unsigned)(wave_min_u64((u64)((unsigned)bd ^ 0x80000000u)) ^ 0x80000000u);
+                wbd = min(wbd, nb);
+#ifdef TSP_STAMPS
+                stamp_hits += 1; stamp_hit_cycles += clock64() - sc0;
+#endif
             }
         };
-        // the row operands are wave-uniform (scalar loads): the next row's are on their way while this row is worked
-        // (positions up to n + 1 exist: k_move_pos pads)
+        // The row operands are wave-uniform: scalar loads, kRowBatch rows per load instruction, and the NEXT batch is on its way
+        // while this one is worked (a scalar load that misses the CU's constant cache takes longer than one row step: with a
+        // prefetch distance of one row the waves spent a quarter of their cycles in s_waitcnt, SQ_WAIT_ANY).  Positions up to
+        // n + kRowBatch exist: k_move_pos pads.
+        struct RowsXY { double2 r[kRowBatch]; };
+        struct RowsE { int e[kRowBatch]; };
         const int p_plain = min(pb, Q0);
         int p = pa + 1;
-        double2 r_next = pxy[p];
-        int e_next = pe[p - 1];
-        for (; p <= p_plain; ++p) {
-            const double2 r = r_next;
-            const int erow = e_next;
-            r_next = pxy[p + 1]; e_next = pe[p];
-            step(p, r, erow, std::false_type{});
-        }
-        for (; p <= pb; ++p) {
-            const double2 r = r_next;
-            const int erow = e_next;
-            r_next = pxy[p + 1]; e_next = pe[p];
-            step(p, r, erow, std::true_type{});
+        RowsXY nx = *reinterpret_cast<const RowsXY *>(pxy + p);
+        RowsE ne = *reinterpret_cast<const RowsE *>(pe + p - 1);
+        for (; p <= pb; p += kRowBatch) {
+            const RowsXY cx4 = nx;
+            const RowsE ce4 = ne;
+            nx = *reinterpret_cast<const RowsXY *>(pxy + p + kRowBatch);
+            ne = *reinterpret_cast<const RowsE *>(pe + p + kRowBatch - 1);
+            if (p + kRowBatch - 1 <= p_plain) {
+#pragma unroll
+                for (int u = 0; u < kRowBatch; ++u) step(p + u, cx4.r[u], ce4.e[u], std::false_type{});
+            } else {
+#pragma unroll
+                for (int u = 0; u < kRowBatch; ++u)
+                    if (p + u <= pb) step(p + u, cx4.r[u], ce4.e[u], std::true_type{});   // the predicate is harmless above the diagonal
+            }
         }
     }
 
     // ---- the wave's, the block's, the tour's arg-min (delta, (i, j)) ------------------------------------------------
+#ifdef TSP_STAMPS
+    if (lane == 0 && tour == 0) {
+        const int w = (int)blockIdx.x * (kScanThreads / 64) + (tid >> 6);
+        if (w < 8192) { g_exh_w[4 * w] = stamp_r0; g_exh_w[4 * w + 1] = wall_clock64(); unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_exh_w[4 * w + 2] = (clock64() - stamp_c0) | ((unsigned long long)hwid << 32); g_exh_w[4 * w + 3] = 1 | (stamp_hits << 8) | ((unsigned long long)(xcc & 0xf) << 60) | ((stamp_hit_cycles & 0xfffffffffull) << 24); }
+    }
+#endif
+    // only the lanes that hold the wave's lowest delta need their pair's node ids (usually one lane: one pair of loads)
     double d = 0.0;
     u64 key = kNoKey;
-    if (bp >= 0) {
-        const int i = pid[bp], j = pid[bq];
-        d = (double)bd;
-        key = make_key(min(i, j), max(i, j));
+    {
+        const int wmin = (int)(unsigned)(wave_min_u64((u64)((unsigned)bd ^ 0x80000000u)) ^ 0x80000000u);
+        if (bp >= 0 && bd == wmin) {
+            const int i = pid[bp], j = pid[bq];
+            d = (double)bd;
+            key = make_key(min(i, j), max(i, j));
+        }
     }
     __shared__ double s_d[kScanThreads / 64];
     __shared__ u64 s_k[kScanThreads / 64];
@@ -212,6 +270,9 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const Ex
     if (tid == 0) {
         publish_partial(a.partials + (size_t)tour * a.partial_per_tour + blockIdx.x, d, key_i(key), key_j(key));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this CU before the ticket
+#ifdef TSP_STAMPS
+        atomicMax(&g_exh_t[4], wall_clock64());
+#endif
         // arrivals on one word are served one after the other: count per cluster of blocks first, then the clusters
         const int Q = ((int)gridDim.x + kExhCluster - 1) / kExhCluster, q = (int)blockIdx.x / kExhCluster;
         const int members = min(kExhCluster, (int)gridDim.x - q * kExhCluster);
@@ -229,6 +290,7 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const Ex
 #ifdef TSP_STAMPS
     __shared__ unsigned long long stamps[16];
     apply_step<WT, INT, TSP_2OPT_BEST, 2, false, true>(a, tour, 0, n - 1, stamps, nullptr);
+    if (tid == 0) atomicMax(&g_exh_t[5], wall_clock64());
 #else
     apply_step<WT, INT, TSP_2OPT_BEST, 2, false, true>(a, tour, 0, n - 1, nullptr);
 #endif

@@ -289,11 +289,12 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
             hipLaunchKernelGGL((k_move_pos<WT, INT>), dim3((t->n + kExhPad + kScanThreads - 1) / kScanThreads, t->B), dim3(kScanThreads), 0, s,
                                t->inst->d_coord, t->d_order, t->d_pos, t->d_order2, t->d_pos2, t->d_state, t->d_pxy, t->d_pe, t->d_pid, t->n);
             a.flat_slots = t->exh_blocks;
-            const ExhArgs x{t->d_pxy, t->d_pe, t->d_pid, t->exh_blocks * (kScanThreads / 64)};
+            const int wt_ = t->exh_blocks * (kScanThreads / 64);
             const dim3 g(t->exh_blocks, 1, t->B);
-            if (t->exh_rj == 4) hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), 0, s, a, x);
-            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), 0, s, a, x);
-            else hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), 0, s, a, x);
+            if (t->exh_rj == 8) hipLaunchKernelGGL((k_exh<WT, INT, 8>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
+            else if (t->exh_rj == 4) hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
+            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
+            else hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
             return TSP_OK;
         }
     }
@@ -814,8 +815,13 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         // the exhaustive sweep in position order (two_opt_exh.hpp): EXH_WAVES waves per SIMD of one tour's grid, all resident
         const int waves = std::max(1, std::min(8, TSP_SW(inst, EXH_WAVES, 4)));
         t->exh_blocks = std::max(1, std::min(2048, inst->ctx->num_cus * waves / std::max(1, B > 4 ? 4 : B)));
+        // One tour: the grid is `waves` workgroups of four waves per CU, and every CU must get exactly that many -- the kernel is
+        // VALU-bound and the waves' shares are equal, so a CU that the dispatcher handed six workgroups finishes 1.5 x later than
+        // the mean (measured: waves leaving their rows between 13 and 40 us, mean 24.6).  Each workgroup therefore asks for
+        // 1 / waves of the CU's LDS (it uses none of it): one more does not fit.
+        if (B == 1 && inst->ctx->lds_bytes >= 65536 && TSP_SW(inst, EXH_EVEN, 1)) t->exh_lds = std::min(65536, inst->ctx->lds_bytes / waves) - 1024;
         const int rj = TSP_SW(inst, EXH_RJ, 2);
-        t->exh_rj = rj == 4 ? 4 : (rj == 1 ? 1 : 2);
+        t->exh_rj = (rj == 8 || rj == 4 || rj == 1) ? rj : 2;
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->exh_blocks);
         const size_t pn = (size_t)B * (inst->n + kExhPad);
         TSP_HIP_TRY(hipMalloc(&t->d_pxy, pn * sizeof(double2)));
@@ -1141,6 +1147,44 @@ int tsp_dev_two_opt_tabu(tsp_dev_inst *inst, tsp_dev_tabu *tabu, int iter, int t
 
 #ifdef TSP_STAMPS
 // diagnostic: mean 100 MHz ticks per segment of the last block of a step; resets the sums
+// diagnostic build: the timeline of the last exhaustive sweep (two_opt_exh.hpp), microseconds after the first wave's start:
+// out[0] last wave start, [1] / [2] / [3] first / mean / last wave out of its rows, [4] last candidate published, [5] apply done,
+// [6] shader clock during the rows (MHz), [7] waves seen
+int tsp_dev_debug_exh_stamps(double *out8) {
+    std::vector<unsigned long long> w(8192 * 4);
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(tsp::g_exh_w), w.size() * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tsp::g_exh_t), sizeof h) != hipSuccess) return -1;
+    unsigned long long t0 = ~0ull, s1 = 0, e0 = ~0ull, e1 = 0;
+    double esum = 0, csum = 0, rsum = 0, hsum = 0, hcsum = 0;
+    int nw = 0;
+    for (int k = 0; k < 8192; ++k) {
+        if (!w[4 * k + 3]) continue;
+        ++nw;
+        t0 = std::min(t0, w[4 * k]); s1 = std::max(s1, w[4 * k]);
+        e0 = std::min(e0, w[4 * k + 1]); e1 = std::max(e1, w[4 * k + 1]);
+        esum += (double)w[4 * k + 1]; csum += (double)(w[4 * k + 2] & 0xffffffffull); rsum += (double)(w[4 * k + 1] - w[4 * k]);
+        hsum += (double)((w[4 * k + 3] >> 8) & 0xffff); hcsum += (double)((w[4 * k + 3] >> 24) & 0xfffffffffull);
+    }
+    if (!nw) return 0;
+    out8[0] = (double)(s1 - t0) / 100.0; out8[1] = (double)(e0 - t0) / 100.0; out8[2] = (esum / nw - (double)t0) / 100.0;
+    out8[3] = (double)(e1 - t0) / 100.0; out8[4] = ((double)h[4] - (double)t0) / 100.0; out8[5] = ((double)h[5] - (double)t0) / 100.0;
+    out8[6] = rsum > 0 ? csum / rsum * 100.0 : 0.0; out8[7] = nw;
+    out8[8] = hsum / nw; out8[9] = hcsum / nw; out8[10] = csum / nw;   // per wave: bookkeeping branches taken, shader cycles in them, cycles in the rows
+    if (const char *dump = getenv("TSP_EXH_DUMP")) {   // per wave: exit time (us after the first start), XCC, HW_ID
+        if (FILE *fp = fopen(dump, "w")) {
+            for (int k = 0; k < 8192; ++k)
+                if (w[4 * k + 3]) fprintf(fp, "%d %.2f %.2f %llu %llu\n", k, (double)(w[4 * k] - t0) / 100.0, (double)(w[4 * k + 1] - t0) / 100.0, w[4 * k + 3] >> 60, w[4 * k + 2] >> 32);
+            fclose(fp);
+        }
+    }
+    std::fill(w.begin(), w.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_exh_w), w.data(), w.size() * 8);
+    const unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_exh_t), z, sizeof z);
+    return nw;
+}
+
 int tsp_dev_debug_stamps(double *out16) {
     unsigned long long h[16], nn = 0;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tsp::g_stamp_sum), sizeof h) != hipSuccess) return -1;
