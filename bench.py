@@ -4,22 +4,20 @@
 Workload (BASELINE.json configs[2], the one the >= 1e9 evals/s target is quoted on): synthetic random EUC_2D,
 n = 10000, numpy default_rng(10000) integer coordinates in [0,1e6)^2, integer costs, single start.
 
-One *step* = ONE FULL best-improvement 2-opt descent (alg_2opt_tabu with skip_edge == NULL, src/tabusearch.c:107-178)
-of the nearest-neighbour tour greedy(start = rank) to its local optimum: 1428 sweeps for rank 0, every sweep deciding
-all n(n-1)/2 - n = 49 985 000 non-adjacent pairs, picking the arg-min, reversing the segment.  The tour is resident in
-HBM (tsp_dev_tours) before the timed region starts; a step restores it device-to-device and runs the product's default
-engine for resident tours (TSP_ENGINE_AUTO -> CLUSTER: 256 workgroups, one descent = one launch).  The final tour is
-checked against the committed golden vector after the timed region.
+The metric as SURVEY.md 8(d) defines it: "steady-state full sweeps in best-improvement mode (every one of 49 985 000 pairs
+evaluated per sweep; evals/s = pairs_evaluated / kernel time), plus end-to-end time-to-local-optimum for both modes".
 
-What the line reports, kept strictly apart:
-  value                               pair evaluations the device EXECUTED per second: pairs for which a lane
-                                      evaluated a lower bound of delta or delta itself (tier counters of the kernel);
-  evals.exact_delta_per_s             delta expressions (tabusearch.c:150) actually executed per second;
-  evals.reference_equivalent_pairs_per_s   pairs DECIDED per second (what the reference would have executed for the
-                                      same, bit-identical decisions) -- most are decided 64 x 64 at a time by a box bound;
-  roofline                            bound "valu": counted floating-point lane-operations of the executed tiers / kernel
-                                      time against the fp64 vector peak, frac <= 1; the same for the exhaustive tiled
-                                      sweep (every delta expression executed) in roofline.exhaustive.
+One *step* of the timed region = ONE FULL best-improvement 2-opt descent (alg_2opt_tabu with skip_edge == NULL,
+src/tabusearch.c:107-178) of the nearest-neighbour tour greedy(start = rank) to its local optimum WITH EVERY DELTA EXPRESSION
+EXECUTED, as the reference executes them: 1428 sweeps for rank 0, each evaluating all n(n-1)/2 - n = 49 985 000 non-adjacent
+pairs exactly (k_move_pos + k_exh, csrc/two_opt_exh.hpp: tour-position order, one new distance per pair), picking the
+arg-min, reversing the segment.  The tour is resident in HBM before the timed region starts; a step restores it
+device-to-device and runs the descent.  The final tour is checked against the committed golden vector after the timed region.
+    value      = delta expressions executed per second, whole job (= sweeps x 49 985 000 x steps x ranks / elapsed)
+    roofline   = that kernel pair: algorithmic operations per launch (35 per delta) over the mean launch
+                 duration measured with HIP events on the engine's stream over the timed region
+The product's default engines decide most pairs by bounds instead of executing them (identical decisions, 5 x faster to the
+local optimum): those descents are reported as time_to_local_optimum (both move-selection rules, parity-checked), never as value.
 With N GPUs each rank refines its own start (weak scaling, no data-path collective); after the timed region the ranks
 run the sharded multi-start configs (BASELINE configs[3], [4]) with one RCCL all-reduce(min) + one broadcast each.
 """
@@ -41,6 +39,9 @@ FP64_LANE_OPS_PEAK = 39.3e12     # 78.6 TFLOP/s fp64 vector (FMA = 2 flops) = 39
 OPS_TIER0_F32 = 11 * 0.5         # dx, dy, dx*dx, fma, two adds for T, T*|T|, two scalings, compare
 OPS_TIER1 = 26.0                 # both new edges without a root: 4 sub, 3 add, 2 x (mul + fma + scale), w, 4 p1 p2, w^2, 3 compares
 OPS_EXACT = 35.0                 # 31 fp64 operations + 4 roots per delta expression
+# what k_exh issues per delta expression (csrc/two_opt_exh.hpp, RJ = 4: 55 VALU instructions per row step of 4 pairs per lane,
+# the four v_sqrt_f64 among them holding the issue port for 4 slots each): ONE distance per pair instead of four
+SLOTS_EXH = (55 + 3 * 4) / 4.0
 OPS_STAGED = 24.0                # one node record: rounded root distance (12) + row culling against a box (12)
 OPS_BOXTEST = 14.0               # one group pair: box gap (6), bound (3), squares and compare (5)
 
@@ -117,32 +118,72 @@ def sharded_configs(E, MS, ctx, rank, world, device, comm=None):
         "collectives": how}
     inst.close()
 
-    # configs[4]: synthetic n = 5000, 128 random individuals (genetic.c:349-364, seed 123) each refined by alg_2opt
-    xy = rand_instance(5000)
-    inst = E.Instance(ctx, xy, E.EUC_2D, 1)
-    rng = MS.LibcRandom(123)
-    perms = np.stack([rng.random_perm(5000) for _ in range(128)])
-    refine = MS.config5_refiner(E, inst, perms)
+    # configs[4]: synthetic n = 5000, 128 random individuals (genetic.c:349-364, seed 123) each refined by alg_2opt -- through the C
+    # host (north star: "host code stays in C"): HEU_2opt_population_multistart of libtsp_host.so draws the individuals on the
+    # libc stream, refines the ones k % world == rank on this rank's device and, with world > 1, runs the collective epilogue
+    # (all-reduce(min) + broadcast over RCCL through the C ABI, failure agreement included) itself
+    import ctypes as C
+    from tsp_optimization_amd.build import lib_path
+    H = C.CDLL(lib_path("libtsp_host.so"))
+
+    class _Edge(C.Structure):
+        _fields_ = [("i", C.c_int), ("j", C.c_int)]
+
+    class _Method(C.Structure):
+        _fields_ = [("id", C.c_int), ("edge_type", C.c_int), ("name", C.c_char_p), ("use_cplex", C.c_int)]
+
+    class _Params(C.Structure):
+        _fields_ = [("file_path", C.c_char_p), ("num_threads", C.c_int), ("time_limit", C.c_int), ("method", _Method), ("verbose", C.c_int),
+                    ("integer_cost", C.c_int), ("seed", C.c_int), ("perf_prof", C.c_int), ("callback_2opt", C.c_int)]
+
+    class _Solution(C.Structure):
+        _fields_ = [("obj_best", C.c_double), ("edges", C.POINTER(_Edge)), ("time_to_solve", C.c_double), ("xbest", C.POINTER(C.c_double))]
+
+    class _Instance(C.Structure):   # include/tsp_host.h == the reference's include/utility.h:147-160
+        _fields_ = [("params", _Params), ("name", C.c_char_p), ("comment", C.c_char_p), ("nodes", C.POINTER(C.c_double)), ("num_nodes", C.c_int),
+                    ("weight_type", C.c_int), ("num_columns", C.c_long), ("ind", C.POINTER(C.c_int)), ("thread_seeds", C.POINTER(C.c_uint)),
+                    ("solution", _Solution)]
+    xy5 = rand_instance(5000)
+    n5, P5 = 5000, 128
+    edges = np.zeros((n5, 2), dtype=np.int32)
+    hi = _Instance()
+    hi.params.time_limit = -1; hi.params.integer_cost = 1; hi.params.seed = 123; hi.params.perf_prof = 1
+    hi.nodes = xy5.ctypes.data_as(C.POINTER(C.c_double)); hi.num_nodes = n5; hi.weight_type = E.EUC_2D
+    hi.num_columns = n5 * (n5 - 1) // 2
+    hi.solution.edges = edges.ctypes.data_as(C.POINTER(_Edge))
+    costs5 = np.full(P5, np.nan)
+    succ5 = np.zeros((P5, n5), dtype=np.int32)
+    st5 = (E.Stats * P5)()
+    bc, bk = C.c_double(0), C.c_int(-1)
+    H.HEU_2opt_population_multistart.argtypes = [C.POINTER(_Instance), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(E.Stats)]
+    C.CDLL(None).srandom(123)
+    if world > 1:   # the C host's rendezvous file must not be the one torch's launcher uses for anything: its own name per job
+        os.environ.setdefault("TSP_RCCL_ID_FILE", "/tmp/tsp_bench_rccl_id.%d.%s" % (os.getuid(), os.environ.get("MASTER_PORT", "0")))
     t0 = time.perf_counter()
-    out = MS.run_sharded(refine, 128, 5000, rank, world, device, comm=comm)
-    t_all = wall(time.perf_counter() - t0)
+    rc5 = H.HEU_2opt_population_multistart(C.byref(hi), P5, rank, world, C.byref(bc), C.byref(bk), costs5.ctypes.data_as(C.POINTER(C.c_double)),
+                                           succ5.ctypes.data_as(C.POINTER(C.c_int)), st5)
+    t_mine = time.perf_counter() - t0
+    t_all = wall(t_mine)
     gold = golden("oracle_vectors_big.json")["config5_rand5000_pop128"]["individuals"]
     best = min(gold, key=lambda r: (r["cost"], r["k"]))
-    ok5 = (out["cost"], out["start"]) == (int(best["cost"]), best["k"])
-    tour5 = fnv1a(out["tour"]) == best["hash"]
-    mine = MS.shard_starts(128, rank, world)
-    ev = int(sum(x["evals"] for x in refine.stats))
-    local5 = all(int(refine.stats[i]["evals"]) == gold[k]["ev"] and int(refine.stats[i]["moves"]) == gold[k]["mv"]
-                 for i, k in enumerate(mine))
+    ok5 = rc5 == 0 and (bc.value, bk.value) == (best["cost"], best["k"])
+    tour5 = fnv1a(edges[:, 1]) == best["hash"]
+    mine = MS.shard_starts(P5, rank, world)
+    local5 = all(costs5[k] == gold[k]["cost"] and fnv1a(succ5[k]) == gold[k]["hash"] and st5[k].evals == gold[k]["ev"] and
+                 st5[k].moves == gold[k]["mv"] and st5[k].sweeps == gold[k]["sw"] for k in mine)
     all5 = wall(0.0 if local5 else 1.0) == 0.0        # max over ranks of "some local individual differs"
     res["config5_rand5000_population128_2opt"] = {
-        "individuals": 128, "individuals_per_rank": out["local_starts"], "wall_s": t_all,
-        "refine_s_max_over_ranks": wall(out["seconds"]), "refine_s_per_rank": per_rank(out["seconds"]), "collectives": how,
-        "best_cost": out["cost"], "best_individual": out["start"],
-        "golden_best": [int(best["cost"]), best["k"]], "rank0_reference_equivalent_evals": ev,
+        "individuals": P5, "individuals_per_rank": len(mine), "wall_s": t_all, "shard_s_per_rank": per_rank(t_mine),
+        "entry": "HEU_2opt_population_multistart(inst, 128, rank, world, ...) of libtsp_host.so (C host: libc draws, fitness, alg_2opt on the "
+                 "shard, RCCL epilogue through tsp_dev_multistart_* when world > 1); wall_s includes the 1.28 M libc draws and the device "
+                 "instance the C host creates for itself",
+        "collectives": "none (1 GPU)" if world == 1 else "all_reduce(min) int64 + broadcast 4n bytes over RCCL, issued by the C host (tsp_host_multistart_epilogue)",
+        "best_cost": bc.value, "best_individual": bk.value, "golden_best": [int(best["cost"]), best["k"]],
+        "rank0_reference_equivalent_evals": int(sum(st5[k].evals for k in mine)),
         "winner_is_the_golden_winner": bool(ok5), "winner_tour_matches_golden": bool(tour5),
-        "every_individual_on_every_rank_matches_golden_counters": bool(all5)}
-    inst.close()
+        "every_individual_on_every_rank_matches_golden_cost_tour_and_counters": bool(all5)}
+    H.tsp_host_shutdown()
     return res
 
 
@@ -322,7 +363,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip everything but the timed region and the roofline")
-    ap.add_argument("--no-variants", action="store_true", help="skip the exhaustive sweeps (keeps a profile clean)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the product's own descents (time_to_local_optimum): keeps a profile of the timed kernel clean")
     args = ap.parse_args()
 
     # --gpus N without a launcher around this process: start the N ranks here, BEFORE anything touches the GPU
@@ -406,18 +447,28 @@ def main():
     start_node = rank % N_NODES
     succ0, obj0, status = inst.construct(E.GREEDY, np.array([start_node], dtype=np.int32))
     assert status[0] == 0
-    tours = E.Tours(inst, 1)
-    tours.upload(succ0[0], obj0[0])          # resident in HBM from here on (and remembered as the reset point)
+    tours = E.Tours(inst, 1)                 # the product's default engines (time_to_local_optimum below)
+    tours.upload(succ0[0], obj0[0])
+    # the timed workload: the same instance with every bound off -- every delta expression of every sweep is executed
+    os.environ["TSP_NO_FILTER"] = "1"
+    inst_x = E.Instance(ctx, xy, wt, 1)
+    tours_x = E.Tours(inst_x, 1)
+    del os.environ["TSP_NO_FILTER"]
+    tours_x.upload(succ0[0], obj0[0])        # resident in HBM from here on (and remembered as the reset point)
+    kernel_x = tours_x.describe(E.BEST)
     pairs_per_sweep = N_NODES * (N_NODES - 1) // 2 - N_NODES
+    dev_ms = []
 
     def one_descent():
-        tours.reset()                        # device-to-device restore of the start tour
-        rc, done = tours.run_engine(E.BEST, engine=E.ENGINE_AUTO)
+        tours_x.reset()                      # device-to-device restore of the start tour
+        rc, done = tours_x.run_engine(E.BEST, engine=E.ENGINE_GRID)
         assert rc == 0 and done
+        dev_ms.append(tours_x.device_ms())   # HIP events on the engine's stream around the run's launches (no wait, no copy)
 
     for _ in range(args.warmup):
         one_descent()
     barrier_sync()
+    del dev_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_descent()
@@ -429,21 +480,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    s_fin, o_fin, st_fin = tours.download()
+    s_fin, o_fin, st_fin = tours_x.download()
     st = st_fin[0]
     # every rank ran `steps` descents of its own start; totals over the job (counters are per descent, identical each step)
-    tot = {k: float(st[k]) for k in ("lane_pairs", "tier1_pairs", "exact_pairs", "staged_recs", "evals", "sweeps")}
+    tot = {k: float(st[k]) for k in ("evals", "sweeps")}
     if dist is not None:
         import torch
         v = torch.tensor([tot[k] for k in sorted(tot)], dtype=torch.float64, device=device)
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         tot = dict(zip(sorted(tot), [float(x) for x in v.tolist()]))
-    counted = st["exact_pairs"] >= 0
-    lane_pairs_job = tot["lane_pairs"] * args.steps
-    value = lane_pairs_job / elapsed
+    value = tot["evals"] * args.steps / elapsed          # delta expressions executed per second, whole job
+    launch_ms = float(np.sum(dev_ms)) / max(1, int(st["sweeps"]) * len(dev_ms))   # mean of one sweep's launches (k_move_pos + k_exh)
 
     # multi-start epilogue of the timed workload: one RCCL all-reduce(min) of the packed (true cost, rank)
-    cost_now, _, packed = tours.best(true_cost=True)
+    cost_now, _, packed = tours_x.best(true_cost=True)
     best_cost, best_rank = int(cost_now), rank
     if dist is not None:
         best_cost, best_rank = MS.allreduce_best(MS.pack(int(cost_now), rank), device=device)
@@ -451,6 +501,7 @@ def main():
             c_cost, c_rank = MS.unpack(comm.allreduce_min(MS.pack(int(cost_now), rank)))
             dist_info["c_abi_allreduce_agrees_with_torch"] = bool((c_cost, c_rank) == (best_cost, best_rank))
 
+    ops_per_launch = pairs_per_sweep * OPS_EXACT
     out = {
         "metric": "2opt_edge_pair_evals_per_sec",
         "value": value,
@@ -468,31 +519,50 @@ def main():
             "workload": "BASELINE configs[2]: synthetic random EUC_2D n=10000 (numpy default_rng(10000), integer coords in "
                         "[0,1e6)^2), single-start 2-opt; step = one full best-improvement descent (alg_2opt_tabu with "
                         "skip_edge == NULL, tabusearch.c:107-178) of greedy(start=rank) to its local optimum on a tour "
-                        "resident in HBM, default engine (TSP_ENGINE_AUTO)",
+                        "resident in HBM, EVERY delta expression of every sweep executed (SURVEY.md 8(d)'s roofline run)",
             "n": N_NODES, "starts_per_gpu": 1, "pairs_per_sweep": pairs_per_sweep, "sweeps_per_step_rank0": int(st["sweeps"]),
-            "step": "device-to-device restore of the start tour + %d sweeps (box / bound / exact tiers) + arg-min + segment "
-                    "reversal each" % int(st["sweeps"]),
+            "step": "device-to-device restore of the start tour + %d sweeps, each: %s, arg-min, segment reversal" % (int(st["sweeps"]), kernel_x),
             "parallelism": "multi-start x%d (one start per GPU, no data-path collective)" % world,
         },
-        "evals": {
-            "definition": "value = pairs for which a lane evaluated a lower bound of delta or delta itself (kernel tier "
-                          "counters), per second, whole job.  NOT counted in value: pairs decided 64 x 64 at a time by the "
-                          "box form of the new-edge bound or by row culling.  reference_equivalent_pairs_per_s counts every "
-                          "pair the reference would have evaluated for the same (bit-identical) decisions.",
-            "counted_on_device": bool(counted),
-            "per_step_rank0": {"lane_pairs_tier0": int(st["lane_pairs"]), "tier1_pairs": int(st["tier1_pairs"]),
-                               "exact_delta_expressions": int(st["exact_pairs"]), "staged_node_records": int(st["staged_recs"]),
-                               "reference_equivalent_pairs": int(st["evals"]), "sweeps": int(st["sweeps"]), "moves": int(st["moves"])},
-            "lane_pairs_per_s": value,
-            "exact_delta_per_s": tot["exact_pairs"] * args.steps / elapsed if counted else None,
-            "reference_equivalent_pairs_per_s": tot["evals"] * args.steps / elapsed,
-        },
-        "time_to_local_optimum_s": elapsed / args.steps,
+        "value_definition": "delta expressions (src/tabusearch.c:150) EXECUTED per second over the timed region, whole job: every one of the "
+                            "49 985 000 non-adjacent pairs of every sweep gets its exact delta; nothing is decided by a bound",
+        "evals": {"per_step_rank0": {"delta_expressions": int(st["evals"]), "sweeps": int(st["sweeps"]), "moves": int(st["moves"])},
+                  "delta_per_s": value, "us_per_sweep_wall": 1e6 * elapsed / args.steps / max(1, int(st["sweeps"]))},
         "multistart_best": dict({"cost": best_cost, "rank": best_rank,
                                  "collective": ("all_reduce(min) int64 over RCCL (torch.distributed and the C ABI's "
                                                 "tsp_dev_multistart_allreduce)") if dist is not None else "none (1 GPU)"},
                                 **dist_info),
+        # the dominant kernel of the timed region, measured live: HIP events on the engine's stream over the timed descents
+        "roofline": {
+            "kernel": "tsp::k_exh<EUC_2D integer-coordinate variant, RJ> (+ tsp::k_move_pos, 4.8 of the ~47 us): one launch pair = one sweep = "
+                      "49 985 000 delta expressions; " + kernel_x,
+            "bound": "valu",
+            "algorithmic_ops_per_launch": ops_per_launch,
+            "launch_ms": launch_ms, "launches_timed": int(st["sweeps"]) * len(dev_ms),
+            "achieved": ops_per_launch / (launch_ms * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
+            "unit": "T lane-op/s (SURVEY 8(d): 35 fp64 operations per delta; peak = fp64 vector 78.6 TFLOP/s / 2 = 39.3 T lane-instructions/s)",
+            "frac": ops_per_launch / (launch_ms * 1e-3) / FP64_LANE_OPS_PEAK,
+            "executed": {
+                "note": "the 35-operation model prices four distances per delta; in tour-position order the second new edge of pair (p, q) "
+                        "is the first new edge of pair (p + 1, q + 1), so k_exh computes ONE distance per delta (every delta still exact): "
+                        "what it issues is %.2f VALU issue slots per delta (55 instructions per 4 pairs, each of the four v_sqrt_f64 "
+                        "holding the port for 4).  frac above is the algorithmic figure the contract asks for and can exceed what a "
+                        "four-distance kernel could reach; issue_frac is the kernel's own utilisation of the VALU issue port" % SLOTS_EXH,
+                "issue_slots_per_delta": SLOTS_EXH,
+                "issue_frac": pairs_per_sweep * SLOTS_EXH / (launch_ms * 1e-3) / FP64_LANE_OPS_PEAK},
+            "operand_bandwidth": {"note": "SURVEY 8(d) also asks for evals/s x 72 B against the HBM peak: with the operands on chip it is not a "
+                                          "roofline (the tour is read once per sweep: 240 KB), reported for completeness",
+                                  "GBps": value * 72.0 / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS},
+            "rocprof": "profiles/r04_kernel_stats_exhaustive.csv, profiles/r04_pmc_sq_exhaustive.json",
+        },
+        "time_to_local_optimum_s": elapsed / args.steps,
     }
+    tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tj):
+        with open(tj) as f:
+            out["roofline"]["traffic"] = json.load(f).get("r04_exhaustive_sweep_n10000_hbm_bytes_per_launch")
+    else:
+        out["roofline"]["traffic"] = None
 
     if rank == 0:
         big = golden("oracle_vectors_big.json")["rand10000_best"]["final"]
@@ -511,60 +581,48 @@ def main():
         except Exception as e:   # noqa: BLE001 -- reported, not swallowed
             out[section] = {"error": repr(e)}
 
-    def roofline_section():
-        # roofline of the dominant kernel of the timed region: one k_cluster_two_opt launch per descent, HIP events on the
-        # engine's stream around a further descent (stats.device_ms), counted lane-operations of the executed tiers
-        one_descent()
-        _, _, st2 = tours.download()
-        kernel_ms = st2[0]["device_ms"]
-        sweeps = st2[0]["sweeps"]
-        ops = (st2[0]["lane_pairs"] * OPS_TIER0_F32 + max(0, st2[0]["tier1_pairs"]) * OPS_TIER1 +
-               max(0, st2[0]["exact_pairs"]) * OPS_EXACT + max(0, st2[0]["staged_recs"]) * OPS_STAGED +
+    def product_section():
+        # time-to-local-optimum of the PRODUCT: the default engine for resident tours (TSP_ENGINE_AUTO -> CLUSTER: 256 workgroups, one
+        # descent = one launch) takes the same decisions as the exhaustive descent above -- same final tour -- but decides most pairs
+        # 64 x 64 at a time by bounds instead of executing their delta
+        ms, wl = [], []
+        for r in range(6):
+            tours.reset()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            rc, done = tours.run_engine(E.BEST, engine=E.ENGINE_AUTO)
+            wl.append(time.perf_counter() - t1)
+            assert rc == 0 and done
+            ms.append(tours.device_ms())
+        s_p, o_p, st_p = tours.download()
+        st2 = st_p[0]
+        big = golden("oracle_vectors_big.json")["rand10000_best"]["final"]
+        kernel_ms = float(np.mean(ms[1:]))
+        sweeps = st2["sweeps"]
+        ops = (st2["lane_pairs"] * OPS_TIER0_F32 + max(0, st2["tier1_pairs"]) * OPS_TIER1 +
+               max(0, st2["exact_pairs"]) * OPS_EXACT + max(0, st2["staged_recs"]) * OPS_STAGED +
                sweeps * (inst_groups(N_NODES) * (inst_groups(N_NODES) + 1) // 2) * OPS_BOXTEST)
-        achieved = ops / (kernel_ms * 1e-3)
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tj):
-            with open(tj) as f:
+        tj2 = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tj2):
+            with open(tj2) as f:
                 traffic = json.load(f).get("r03_cluster_descent_n10000_hbm_bytes_per_launch")
-        exhaustive = {}
-        if not args.no_variants:
-            # the same sweep with every delta expression executed (tiled kernel k_recs + k_step, bounds off): the kernel
-            # whose work IS the reference's 49 985 000 evaluations per launch, VALU-throughput bound
-            os.environ["TSP_NO_FILTER"] = "1"
-            inst_v = E.Instance(ctx, xy, wt, 1)
-            tours_v = E.Tours(inst_v, 1)
-            del os.environ["TSP_NO_FILTER"]
-            tours_v.upload(succ0[0], obj0[0])
-            ms_v, ev_v = tours_v.time_scan(reps=40)
-            exhaustive = {"kernel": "tsp::k_recs + tsp::k_step<EUC_2D icoord, BEST> with the bounds off (TSP_NO_FILTER=1): every "
-                                    "non-adjacent pair gets the exact delta", "kernel_ms": ms_v, "delta_expressions_per_launch": ev_v,
-                          "exact_delta_per_s": ev_v / (ms_v * 1e-3), "bound": "valu", "ops_per_eval": OPS_EXACT,
-                          "achieved": ev_v * OPS_EXACT / (ms_v * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
-                          "unit": "T lane-op/s", "frac": ev_v * OPS_EXACT / (ms_v * 1e-3) / FP64_LANE_OPS_PEAK,
-                          "rocprof": "profiles/r03_kernel_stats_exhaustive.csv"}
-            tours_v.close()
-            inst_v.close()
-        out["roofline"] = {
-            "kernel": "tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, BEST, float replica, sorted scan> -- one launch = "
-                      "one whole descent (%d sweeps) on 256 workgroups; kernel_ms = HIP events on the engine's stream around one "
-                      "further descent after the timed region (rocprof mean: profiles/r03_kernel_stats.csv)" % sweeps,
-            "bound": "valu", "achieved": achieved / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
-            "unit": "T lane-op/s (fp64 vector lane-instructions; peak = 78.6 TFLOP/s / 2; fp32 operations count 1/2)",
-            "frac": achieved / FP64_LANE_OPS_PEAK, "traffic": traffic,
-            "kernel_ms": kernel_ms, "us_per_sweep": 1e3 * kernel_ms / sweeps, "counted_lane_ops_per_launch": ops,
-            "ops_per_unit": {"tier0_pair_f32": OPS_TIER0_F32, "tier1_pair": OPS_TIER1, "exact_delta": OPS_EXACT,
-                             "staged_record": OPS_STAGED, "group_pair_box_test": OPS_BOXTEST},
-            "operand_bandwidth": {"note": "SURVEY 8(d) also asks for evals/s x 72 B against the HBM peak: with the operands "
-                                          "on chip it is not a roofline (the tour is read once per launch), reported for completeness",
-                                  "reference_equivalent_GBps": st2[0]["evals"] * 72.0 / (kernel_ms * 1e-3) / 1e9,
-                                  "executed_lane_pairs_GBps": st2[0]["lane_pairs"] * 72.0 / (kernel_ms * 1e-3) / 1e9,
-                                  "hbm_peak_GBps": HBM_PEAK_GBS},
-            "note": "the step is a chain of latencies (LDS gathers at two waves per SIMD, one all-to-all exchange through L2 per "
-                    "sweep, block barriers), not a throughput kernel: the executed arithmetic is ~1-2 % of the VALU peak by "
-                    "design -- see DESIGN.md 4.8; roofline.exhaustive is the same sweep with nothing pruned",
-            "exhaustive": exhaustive,
-        }
+        out["time_to_local_optimum"] = {"best_improvement_alg_2opt_tabu": {
+            "engine": "TSP_ENGINE_AUTO -> CLUSTER: tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, BEST, float replica, sorted scan>, "
+                      "one launch = the whole descent on 256 workgroups",
+            "device_ms": kernel_ms, "wall_ms": 1e3 * float(np.mean(wl[1:])), "sweeps": int(sweeps), "us_per_sweep": 1e3 * kernel_ms / sweeps,
+            "final_cost": float(o_p[0]), "moves": int(st2["moves"]),
+            "final_tour_matches_golden": bool(fnv1a(s_p[0]) == big["hash"] and o_p[0] == big["cost"] and st2["sweeps"] == big["stats"]["sweeps"]
+                                              and st2["evals"] == big["stats"]["evals"] and st2["moves"] == big["stats"]["moves"]),
+            "pairs_decided_per_s": st2["evals"] / (kernel_ms * 1e-3),
+            "executed_per_descent": {"lane_pairs_tier0": int(st2["lane_pairs"]), "tier1_pairs": int(st2["tier1_pairs"]),
+                                     "exact_delta_expressions": int(st2["exact_pairs"]), "staged_node_records": int(st2["staged_recs"])},
+            "valu_frac_of_executed_work": ops / (kernel_ms * 1e-3) / FP64_LANE_OPS_PEAK,
+            "hbm_bytes_per_launch": traffic,
+            "note": "a chain of latencies by design (LDS gathers, one all-to-all exchange through L2 per sweep, block barriers), DESIGN.md 4.8: "
+                    "it decides 5.9e12 pairs per second while executing ~1 k delta expressions per sweep -- which is why it is not the "
+                    "evals/s headline",
+            "rocprof": "profiles/r03_kernel_stats.csv (12.11 ms mean), profiles/r03_pmc_sq_wave_counters.json"}}
 
     def first_section():
         # the north star's named function, alg_2opt (first improvement, heuristics.c:438-502), on a resident tour: the
@@ -591,32 +649,22 @@ def main():
         ops = (stf["lane_pairs"] * OPS_TIER0_F32 + max(0, stf["tier1_pairs"]) * OPS_TIER1 + max(0, stf["exact_pairs"]) * OPS_EXACT +
                max(0, stf["staged_recs"]) * OPS_STAGED)
         kms = float(np.mean(ms))
-        out["roofline"]["first"] = {
-            "kernel": "tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, FIRST, float replica, plain | rank order>: one descent = "
-                      "a few launches (hand-overs between the two variants); device_ms = HIP events on the engine's stream around "
-                      "all of them (rocprof: profiles/r03_kernel_stats_first.csv)",
-            "bound": "valu", "device_ms": kms, "steps": int(stf["steps"]), "us_per_step": 1e3 * kms / max(1, stf["steps"]),
+        out["time_to_local_optimum"]["first_improvement_alg_2opt"] = {
+            "engine": "TSP_ENGINE_AUTO -> CLUSTER: tsp::k_cluster_two_opt<EUC_2D integer-coordinate variant, FIRST, float replica, plain | rank order>: "
+                      "one descent = a few launches (hand-overs between the two variants); device_ms = HIP events on the engine's stream "
+                      "around all of them (rocprof: profiles/r03_kernel_stats_first.csv)",
+            "device_ms": kms, "steps": int(stf["steps"]), "us_per_step": 1e3 * kms / max(1, stf["steps"]),
             "sweeps": int(stf["sweeps"]), "reference_evals": int(stf["evals"]), "moves": int(stf["moves"]),
             "reference_counters_match": bool((stf["sweeps"], stf["evals"], stf["moves"]) == (10, 499850987, 2704) and of[0] == 77370387),
-            "counted_lane_ops_per_descent": ops, "achieved": ops / (kms * 1e-3) / 1e12, "peak": FP64_LANE_OPS_PEAK / 1e12,
-            "frac": ops / (kms * 1e-3) / FP64_LANE_OPS_PEAK, "unit": "T lane-op/s",
+            "valu_frac_of_executed_work": ops / (kms * 1e-3) / FP64_LANE_OPS_PEAK,
             "reference_equivalent_evals_per_s": stf["evals"] / (kms * 1e-3),
             "sweep_that_finds_nothing_us_per_call": 1e6 * float(np.mean(t_nohit[2:])),
             "note": "a chain of 2 704 dependent moves: 5.8 us per step, 3.1 of it one all-to-all exchange (DESIGN.md 4.8, 4.8c)"}
 
-    if rank == 0:
-        guarded("roofline", roofline_section)
-        if "error" not in out.get("roofline", {"error": 1}):
-            guarded("roofline_first", first_section)
-            ex = out["roofline"].get("exhaustive") or {}
-            # the three rates the metric can mean, side by side at the top level
-            out["value_definition"] = ("lane_pairs: pairs for which a lane executed a lower bound of delta or delta itself, per second, "
-                                       "timed region, whole job")
-            out["value_note"] = ("value counts the pairs that reach a lane's tier 0: better pruning LOWERS it (round 2: 1.45e11 in 16.2 ms per descent; "
-                                 "round 3's quarter units send 62 % fewer pairs there: 6.4e10 in 12.2 ms, the same decisions).  Compare ms_per_step, "
-                                 "time_to_local_optimum and reference_equivalent_pairs_per_s across rounds, not value")
-            out["delta_evals_per_s_exhaustive"] = ex.get("exact_delta_per_s")
-            out["reference_equivalent_pairs_per_s"] = out["evals"]["reference_equivalent_pairs_per_s"]
+    if rank == 0 and not args.no_variants:
+        guarded("time_to_local_optimum", product_section)
+        if "error" not in out.get("time_to_local_optimum", {"error": 1}):
+            guarded("time_to_local_optimum_first", first_section)
 
     def extras_section():
         extras = {}
@@ -637,7 +685,7 @@ def main():
         extras["best_improvement_alg_2opt_tabu_host_tour"] = {
             "time_to_local_optimum_s": dt2, "device_ms": st2["device_ms"], "final_cost": o2, "sweeps": st2["sweeps"],
             "moves": st2["moves"], "note": "host tour in, host tour out (PCIe-inclusive)"}
-        out["time_to_local_optimum"] = extras
+        out.setdefault("time_to_local_optimum", {})["host_tour_in_host_tour_out"] = extras
         # the genuinely HBM-bound kernel of the path: n x n calc_dist matrix (4 n^2 bytes written)
         _, dm_ms = inst.dist_matrix(as_int32=True, fetch=False)
         _, dm64_ms = inst.dist_matrix(as_int32=False, fetch=False)
@@ -657,9 +705,12 @@ def main():
                 r3 = json.load(f).get("r03_dist_matrix")
             if r3:   # rocprofv3 evidence of the same kernel (profiles/r03_*): mean duration and WRITE_SIZE per launch
                 for k in ("int32", "f64"):
-                    out["distance_matrix_build"][k].update({
-                        "rocprof_mean_us": r3[k]["rocprof_mean_us"], "write_size_bytes": r3[k]["write_size_bytes"],
-                        "hbm_frac_write_size_over_rocprof_time": r3[k]["write_size_bytes"] / (r3[k]["rocprof_mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                    d = out["distance_matrix_build"][k]
+                    # the roofline figure: measured HBM write traffic over the profiler's kernel time.  The HIP-event rate of
+                    # back-to-back launches reads up to 7 % higher (head / tail overlap of consecutive launches, not bandwidth)
+                    d.update({"rocprof_mean_us": r3[k]["rocprof_mean_us"], "write_size_bytes": r3[k]["write_size_bytes"],
+                              "hip_event_frac_this_run": d["frac"],
+                              "frac": r3[k]["write_size_bytes"] / (r3[k]["rocprof_mean_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS})
                 out["distance_matrix_build"]["rocprof"] = r3["source"]
 
     def tabu_section():
@@ -724,7 +775,7 @@ def main():
         out["alg_2opt_tabu_with_a_list"] = res
 
     if rank == 0 and world == 1 and not args.no_extras:
-        guarded("time_to_local_optimum", extras_section)
+        guarded("time_to_local_optimum_host_tours", extras_section)
         guarded("alg_2opt_tabu_with_a_list", tabu_section)
 
     if not args.no_extras:
@@ -749,8 +800,7 @@ def main():
         out["cpu_baseline"] = {
             "value": base["best_improvement"]["evals_per_s"], "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": base["best_improvement"]["sample"] + " by oracle/tsp_oracle.c (gcc -O2), one thread, %.1f s: every "
-                      "delta expression executed (compare with evals.reference_equivalent_pairs_per_s and "
-                      "roofline.exhaustive.exact_delta_per_s); the reference is single-threaded and cannot be built here "
+                      "delta expression executed (the same unit as `value`); the reference is single-threaded and cannot be built here "
                       "(needs cplex.h)" % base["best_improvement"]["seconds"],
             "others": {k: v for k, v in base.items() if k != "best_improvement"},
         }
@@ -759,6 +809,8 @@ def main():
         guarded("cpu_baseline", cpu_section)
 
     tours.close()
+    tours_x.close()
+    inst_x.close()
     inst.close()
     if comm is not None:
         comm.close()

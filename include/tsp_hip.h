@@ -232,6 +232,9 @@ int tsp_dev_tours_restore(tsp_dev_tours *t);
  * launches in *mean_ms and the reference-equivalent evaluations per step in *evals_per_launch.
  * Roofline measurement. */
 int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t *evals_per_launch);
+/* Device time of the last tsp_dev_tours_run_engine / tsp_dev_tours_two_opt on this handle (HIP events on the engine's stream
+ * around the run; the same value tsp_dev_tours_download reports as stats.device_ms), without a copy or a wait. */
+int tsp_dev_tours_device_ms(tsp_dev_tours *t, double *ms);
 /* Diagnostics: the kernels one GRID-engine step of `mode` launches for this handle, as text (bench.py names the kernel its
  * roofline describes from this; tests check that a switch selected the path they mean to test). */
 int tsp_dev_tours_describe(tsp_dev_tours *t, int mode, char *buf, int cap);

@@ -58,7 +58,7 @@ constexpr int kApplyThreads = 1024;
     X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
     X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \
     X(CONSTRUCT_NN) X(LDS_PAIR) X(CLUSTER_FS_ROWS) X(CLUSTER_LPT) X(CLUSTER_B0) X(LDS_F32_MIN_N) X(CLUSTER_DEFER)          \
-    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN)
+    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN) X(EXH_PRIO)
 namespace tsp {
 enum SwitchId {
 #define TSP_SW_ENUM(name) SW_##name,
@@ -164,7 +164,7 @@ struct tsp_dev_tours {
     double2 *d_pxy = nullptr;
     int *d_pe = nullptr, *d_pid = nullptr;
     int exh_lds = 0;                 // k_exh: dynamic LDS a workgroup asks for (unused; it pins the number of workgroups per CU)
-    int exh_blocks = 0, exh_rj = 2;  // k_exh: workgroups per tour (0: the tiled k_step executes the exhaustive sweep), columns per lane
+    int exh_blocks = 0, exh_rj = 4, exh_prio = 1;  // k_exh: workgroups per tour (0: the tiled k_step executes the exhaustive sweep), columns per lane
     int *d_pairtab = nullptr;        // group pairs per cluster of k_sweep blocks (host-built), or nullptr
     int *d_ticket = nullptr;         // per tour: scan blocks still to arrive in the current step
     int *d_row_ticket = nullptr;     // per tour x tile row (BEST two-level hand-off)

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kScanThreads) void k_move_pos(const double2 *__rest
 
 template <int WT, bool INT, int RJ>
 __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const double2 *__restrict__ pxy_all, const int *__restrict__ pe_all,
-                                                      const int *__restrict__ pid_all, int waves_total) {
+                                                      const int *__restrict__ pid_all, int waves_total, int prio_on) {
     // the position arrays are kernel arguments of their own, restrict-qualified: the row operands are wave-uniform loads, and
     // the compiler only issues them as scalar loads (s_load: no vector-memory slot, no VGPRs) when it can prove that the
     // kernel's own stores and atomics (candidate slots, tickets) never touch them
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const do
         if (u_lo >= cum + rows_s) { cum += rows_s; continue; }
         // segment of strip s: pair-rows [pa, pb)
         const int pa = (int)(u_lo - cum), pb = (int)min<long long>(rows_s, u_hi - cum);
+        const long long u_lo_now = u_lo;
         u_lo = cum + pb;
         cum += rows_s;
         const int Q0 = s * WEFF;
@@ -227,6 +228,17 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const do
         RowsXY nx = *reinterpret_cast<const RowsXY *>(pxy + p);
         RowsE ne = *reinterpret_cast<const RowsE *>(pe + p - 1);
         for (; p <= pb; p += kRowBatch) {
+            // A SIMD serves its oldest wave first: left alone, the four waves of a SIMD leave their rows one after the other
+            // (13, 21, 29, 36 us measured) and the last one runs alone, latency-bound, at half the issue rate.  Every wave has
+            // the same number of rows, so a wave raises its priority with the share of them it still has to do: whoever is
+            // behind goes first, and the waves of a SIMD finish together.
+            if (prio_on) {
+                const int lvl = (int)min<long long>(3, (u_hi - u_lo_now - (p - pa - 1)) * 4 / per);
+                if (lvl >= 3) __builtin_amdgcn_s_setprio(3);
+                else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+                else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             const RowsXY cx4 = nx;
             const RowsE ce4 = ne;
             nx = *reinterpret_cast<const RowsXY *>(pxy + p + kRowBatch);

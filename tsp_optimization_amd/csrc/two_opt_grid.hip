@@ -291,10 +291,10 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
             a.flat_slots = t->exh_blocks;
             const int wt_ = t->exh_blocks * (kScanThreads / 64);
             const dim3 g(t->exh_blocks, 1, t->B);
-            if (t->exh_rj == 8) hipLaunchKernelGGL((k_exh<WT, INT, 8>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
-            else if (t->exh_rj == 4) hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
-            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
-            else hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_);
+            if (t->exh_rj == 8) hipLaunchKernelGGL((k_exh<WT, INT, 8>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
+            else if (t->exh_rj == 2) hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
+            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
+            else hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
             return TSP_OK;
         }
     }
@@ -820,8 +820,9 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         // the mean (measured: waves leaving their rows between 13 and 40 us, mean 24.6).  Each workgroup therefore asks for
         // 1 / waves of the CU's LDS (it uses none of it): one more does not fit.
         if (B == 1 && inst->ctx->lds_bytes >= 65536 && TSP_SW(inst, EXH_EVEN, 1)) t->exh_lds = std::min(65536, inst->ctx->lds_bytes / waves) - 1024;
-        const int rj = TSP_SW(inst, EXH_RJ, 2);
-        t->exh_rj = (rj == 8 || rj == 4 || rj == 1) ? rj : 2;
+        const int rj = TSP_SW(inst, EXH_RJ, 4);
+        t->exh_prio = TSP_SW(inst, EXH_PRIO, 1);
+        t->exh_rj = (rj == 8 || rj == 2 || rj == 1) ? rj : 4;
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->exh_blocks);
         const size_t pn = (size_t)B * (inst->n + kExhPad);
         TSP_HIP_TRY(hipMalloc(&t->d_pxy, pn * sizeof(double2)));
@@ -989,6 +990,12 @@ int tsp_dev_tours_time_scan(tsp_dev_tours *t, int reps, float *mean_ms, int64_t 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (mean_ms) *mean_ms = (float)(total / reps);
     if (evals_per_launch) *evals_per_launch = ((int64_t)n * (n - 1) / 2 - n) * t->B;
+    return TSP_OK;
+}
+
+int tsp_dev_tours_device_ms(tsp_dev_tours *t, double *ms) {
+    if (!t || !ms) return TSP_DEV_E_ARG;
+    *ms = t->device_ms;
     return TSP_OK;
 }
 

@@ -88,6 +88,7 @@ def lib():
         L.tsp_dev_tours_restore.argtypes = [vp]
         L.tsp_dev_tours_time_scan.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         L.tsp_dev_tours_describe.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+        L.tsp_dev_tours_device_ms.argtypes = [vp, C.POINTER(C.c_double)]
         L.tsp_dev_tours_best.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
         L.tsp_dev_comm_last_error.restype = C.c_char_p
         L.tsp_dev_comm_unique_id.argtypes = [C.c_char_p]
@@ -114,7 +115,7 @@ EXPORTED = [
     "tsp_dev_tabu_create", "tsp_dev_tabu_destroy", "tsp_dev_tabu_set", "tsp_dev_tabu_get",
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
-    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best", "tsp_dev_tours_describe",
+    "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best", "tsp_dev_tours_describe", "tsp_dev_tours_device_ms",
     "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
     "tsp_dev_comm_last_error", "tsp_dev_comm_available", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
@@ -354,6 +355,12 @@ class Tours:
         rc = lib().tsp_dev_tours_run(self._h, mode, max_steps, time_limit, 1 if sync else 0, C.byref(done))
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
         return rc, bool(done.value)
+
+    def device_ms(self):
+        """Device time of the last run_engine / two_opt on this handle (HIP events on the engine's stream)."""
+        ms = C.c_double(0)
+        _check(lib().tsp_dev_tours_device_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def describe(self, mode):
         """The kernels one GRID-engine step of `mode` launches for this handle."""
