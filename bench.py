@@ -746,32 +746,52 @@ def main():
         inst.reload_switches()
         res["four_stamp_reads_per_pair"]["hbm_frac"] = res["four_stamp_reads_per_pair"]["those_bytes_per_s_GBps"] / HBM_PEAK_GBS
         res["live_stamps"] = live
-        # iterations of tabu() (tabusearch.c:238-309) on resident state: alg_2opt_tabu + incumbent + kick per iteration
-        tb = E.Tabu(inst)
-        tt = E.Tours(inst, 1)
-        tt.upload(s_t[0], o)                      # the local optimum reached above
-        krng = np.random.default_rng(11)
-        best, iters, tenure = float("inf"), 400, 200
-        def one(it):
-            nonlocal best
-            a, b = int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES))
-            rc, obj, best, improved, acc = tt.tabu_iteration(tb, it, tenure, a, b, best)
-            while not acc:
-                acc = tt.tabu_kick(tb, int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES)), it, tenure)
-        for it in range(1, 41):
-            one(it)
-        ctx.synchronize()
-        t1 = time.perf_counter()
-        for it in range(41, 41 + iters):
-            one(it)
-        ctx.synchronize()
-        dt = time.perf_counter() - t1
-        _, _, st_d = tt.download()
-        res["tabu_iterations_on_resident_state"] = {"iterations": iters, "seconds": dt, "iterations_per_s": iters / dt,
-                                                    "tenure": tenure, "incumbent": best, "list_entries": tb.list_info()[0],
-                                                    "worked_from_the_list": tb.list_info()[1],
-                                                    "sweeps_per_iteration": (st_d[0]["sweeps"]) / float(iters + 40)}
-        tb.close(); tt.close()
+        # iterations of tabu() (tabusearch.c:238-309) on resident state: alg_2opt_tabu + incumbent + kick per iteration, the way the C
+        # host's tsp_host_tabu drives them -- chains of 32 iterations per wait for the device (tsp_dev_tours_tabu_iterations), a chain
+        # stopping where a kick's first trial is rejected -- and, next to it, one iteration per wait (round 3's form)
+        def tabu_loop(chain):
+            tb = E.Tabu(inst)
+            tt = E.Tours(inst, 1)
+            tt.upload(s_t[0], o)                      # the local optimum reached above
+            krng = np.random.default_rng(11)
+            state = {"best": float("inf"), "it": 1, "waits": 0}
+            tenure = 200
+
+            def run(iters):
+                end = state["it"] + iters
+                while state["it"] < end:
+                    K = min(chain, end - state["it"])
+                    ab = krng.integers(0, N_NODES, size=(K, 2)).astype(np.int32)
+                    if K > 1:
+                        rc, done, acc, state["best"], _, _ = tt.tabu_iterations(tb, state["it"], [tenure] * K, ab, state["best"])
+                    else:
+                        done = 0
+                    if done == 0:
+                        rc, obj, state["best"], improved, acc = tt.tabu_iteration(tb, state["it"], tenure, int(ab[0, 0]), int(ab[0, 1]), state["best"])
+                        done = 1
+                    state["waits"] += 1
+                    last = state["it"] + done - 1
+                    while not acc:
+                        acc = tt.tabu_kick(tb, int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES)), last, tenure)
+                    state["it"] = last + 1
+            run(40)
+            ctx.synchronize()
+            state["waits"] = 0
+            t1 = time.perf_counter()
+            run(iters)
+            ctx.synchronize()
+            dt = time.perf_counter() - t1
+            _, _, st_d = tt.download()
+            r = {"iterations": iters, "seconds": dt, "iterations_per_s": iters / dt, "tenure": tenure, "incumbent": state["best"],
+                 "list_entries": tb.list_info()[0], "worked_from_the_list": tb.list_info()[1], "waits_for_the_device": state["waits"],
+                 "sweeps_per_iteration": (st_d[0]["sweeps"]) / float(iters + 40)}
+            tb.close(); tt.close()
+            return r
+        iters = 400
+        res["tabu_iterations_on_resident_state"] = dict(tabu_loop(32), chain="32 iterations queued per wait (tsp_dev_tours_tabu_iterations)")
+        res["tabu_iterations_on_resident_state"]["one_iteration_per_wait"] = tabu_loop(1)
+        same = res["tabu_iterations_on_resident_state"]["incumbent"] == res["tabu_iterations_on_resident_state"]["one_iteration_per_wait"]["incumbent"]
+        res["tabu_iterations_on_resident_state"]["same_incumbent_both_ways"] = bool(same)
         out["alg_2opt_tabu_with_a_list"] = res
 
     if rank == 0 and world == 1 and not args.no_extras:

@@ -217,6 +217,18 @@ int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, 
  * no kick is made (:255-258).  obj / improved / accepted may be NULL. */
 int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
                                  double *best_obj, double *obj, int *improved, int *accepted);
+/* `count` (<= 64) iterations of tabu() in ONE wait for the device: iteration iter0 + k runs alg_2opt_tabu with tenure[k], updates
+ * the incumbent and makes the FIRST trial of its kick with the host-drawn nodes ab[2k], ab[2k + 1] (what
+ * tsp_dev_tours_tabu_iteration does for one iteration) -- the launches are queued back to back and a word on the device stops the
+ * chain as soon as an iteration cannot be completed there.  *completed = iterations that ran up to their kick's trial; obj[k] /
+ * improved[k] are filled for those.  *last_accepted = 0: the trial of iteration iter0 + *completed - 1 was rejected (edges that
+ * share a node, or tabu): the caller draws further trials for it (tsp_dev_tours_tabu_kick) and goes on; the pairs ab[2k ..] of
+ * the iterations that did not run have not been consumed (the caller serves them first: the libc stream stays the
+ * reference's).  An iteration whose descent did not finish inside its launch (or whose exchange gave up) is not counted: the
+ * caller runs it through tsp_dev_tours_tabu_iteration with its own a, b.  *completed = 0 with return 0: the chain does not
+ * apply here (another engine, a list too long for it); nothing was touched. */
+int tsp_dev_tours_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab,
+                                  double time_limit_s, double *best_obj, double *obj, int *improved, int *completed, int *last_accepted);
 /* kick() of src/vns.c:11-100 with the three host-drawn, sorted tour positions p1 < p2 < p3 (positions of the walk from
  * node 0): segments tour[p1+1..p2] and tour[p2+1..p3] swap places; the recomputed cost (:77-86) goes to the control block
  * and to *obj (may be NULL). */

@@ -208,6 +208,10 @@ int tsp_host_genetic_ex(instance *inst, long long max_generations, double two_op
 /* ... and with the offspring that drew mutation 3 spread over devices 0 .. gpus-1 (a contiguous block of them per GPU, one thread per GPU
  * and generation, context and instance per GPU kept for the whole run); gpus <= 0: this process's device as above.  The CLI's -gpus G. */
 int tsp_host_genetic_gpus(instance *inst, long long max_generations, double two_opt_prob, int gpus);
+/* Values of the libc stream that this library has drawn ahead of their turn and not consumed yet (tsp_host_tabu queues chains
+ * of iterations and needs every iteration's first kick draws up front; what a chain leaves unconsumed is served first by every
+ * later draw of this library: URAND() of this build, rand_choice()).  0 whenever a capped run (max_iterations) has returned. */
+int tsp_host_random_lookahead(void);
 /* Counters of the last alg_2opt / alg_2opt_tabu call of this thread. */
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms);
 /* Releases the cached device context / instances (optional; also done at exit). */

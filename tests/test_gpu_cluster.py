@@ -418,3 +418,58 @@ def test_sorted_scan_on_256_workgroups_equals_the_grid_engine_at_mid_sizes(eng, 
         assert (st1["sweeps"], st1["evals"], st1["moves"], st1["reversed"]) == (st3["sweeps"], st3["evals"], st3["moves"], st3["reversed"])
         assert O.succ_cost(xy, wt, s3) == o3
     inst.close()
+
+
+def test_chain_of_tabu_iterations_equals_the_iterations_one_by_one(eng, ctx):
+    """tsp_dev_tours_tabu_iterations: K iterations of tabu() queued back to back (one wait for the device) against the same K
+    iterations through tsp_dev_tours_tabu_iteration, on two handles that start alike: same costs, same incumbent, same tour,
+    same stamps.  A chain stops at the first iteration whose kick is rejected (here forced: a == b) -- the iterations behind it
+    must not have run (tour and stamps as after the one-by-one replay up to that point), and the caller's next kick finishes
+    the iteration."""
+    xy, wt = load_instance("pr1002")
+    n = len(xy)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    rng = np.random.default_rng(5)
+    K = 12
+    tenures = [20 + (k % 3) for k in range(K)]
+    ab = rng.integers(0, n, size=(K, 2)).astype(np.int32)
+    ab[7] = (123, 123)                                   # a == b: rejected (tabusearch.c:271-273)
+
+    def handle():
+        t, tb = eng.Tours(inst, 1), eng.Tabu(inst)
+        t.upload(succ0, obj0)
+        return t, tb
+    t1, tb1 = handle()
+    t2, tb2 = handle()
+    # one by one up to and including the rejected trial of iteration 8
+    best, objs = float("inf"), []
+    for k in range(8):
+        rc, obj, best, improved, acc = t1.tabu_iteration(tb1, 1 + k, tenures[k], int(ab[k, 0]), int(ab[k, 1]), best)
+        assert rc == 0 and acc == (k != 7)
+        objs.append(obj)
+    # the chain: 12 queued, 8 run, the last one's trial rejected
+    rc, done, last_acc, best2, obj2, imp2 = t2.tabu_iterations(tb2, 1, tenures, ab, float("inf"))
+    assert rc == 0 and done == 8 and not last_acc
+    assert list(obj2) == objs and best2 == best
+    sa, oa, _ = t1.download()
+    sb, ob, _ = t2.download()
+    assert (sa[0] == sb[0]).all() and (tb1.download() == tb2.download()).all()
+    # the caller finishes iteration 8 with further trials, then goes on: a second chain from iteration 9
+    for t, tb in ((t1, tb1), (t2, tb2)):
+        assert t.tabu_kick(tb, 5, 700, 8, tenures[7])
+    rest = ab[8:]
+    for k in range(8, K):
+        rc, obj, best, improved, acc = t1.tabu_iteration(tb1, 1 + k, tenures[k], int(ab[k, 0]), int(ab[k, 1]), best)
+        assert rc == 0 and acc
+    rc, done, last_acc, best2, obj2, imp2 = t2.tabu_iterations(tb2, 9, tenures[8:], rest, best2)
+    assert rc == 0 and done == K - 8 and last_acc and best2 == best
+    sa, oa, _ = t1.download()
+    sb, ob, _ = t2.download()
+    assert (sa[0] == sb[0]).all() and oa[0] == ob[0] and (tb1.download() == tb2.download()).all()
+    # the incumbents kept on the device are the same tour
+    t1.restore(); t2.restore()
+    assert (t1.download()[0][0] == t2.download()[0][0]).all()
+    for x in (t1, t2, tb1, tb2):
+        x.close()
+    inst.close()

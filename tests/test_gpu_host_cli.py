@@ -44,6 +44,7 @@ def host():
     L.HEU_Grasp_iter.argtypes = [C.POINTER(Instance), C.c_int]
     L.HEU_2opt_grasp_iter.argtypes = [C.POINTER(Instance)]
     L.tsp_host_last_grasp_iter_starts.restype = C.c_longlong
+    L.tsp_host_random_lookahead.restype = C.c_int
     yield L
     L.tsp_host_shutdown()
 
@@ -240,6 +241,31 @@ def test_tabu_iterations_match_oracle(host, policy):
     es, eo, moves = O.tabu(h.xy, h.wt, s1, o1, 120, policy)
     assert rc == 0 and h.obj == eo and (h.succ == es).all() and moves > 0
     assert h.obj == O.succ_cost(h.xy, h.wt, h.succ)
+
+
+@pytest.mark.parametrize("policy,chain", [(0, "1"), (0, "5"), (1, "32"), (2, "7"), (2, "64")])
+def test_tabu_chains_give_the_oracles_search_and_leave_the_libc_stream_where_it_leaves_it(host, policy, chain, monkeypatch):
+    """tsp_host_tabu queues TSP_TABU_CHAIN iterations per wait for the device (tsp_dev_tours_tabu_iterations) and therefore draws
+    every iteration's first kick nodes before the chain runs; a chain stops at the first rejected kick (at n = 299 about one
+    trial in six is rejected: shared nodes, tabu edges) and the draws of the iterations that did not run go back to the head
+    of the stream.  Whatever the chain length: the oracle's incumbent after 150 iterations (tour, cost) -- and the NEXT value
+    of libc's random() after the run equals the one after the oracle's run, i.e. exactly the reference's number of draws was
+    consumed, in its order (the policy's own draws, random policy, included)."""
+    monkeypatch.setenv("TSP_TABU_CHAIN", chain)
+    libc = C.CDLL(None)
+    libc.random.restype = C.c_long
+    h = HostInstance("pr299")
+    h.c.params.time_limit = 600
+    O.srandom(123)
+    rc = host.tsp_host_tabu(C.byref(h.c), policy, 150)
+    assert host.tsp_host_random_lookahead() == 0
+    next_host = libc.random()
+    s1, o1 = _initial(h)
+    O.srandom(123)
+    es, eo, moves = O.tabu(h.xy, h.wt, s1, o1, 150, policy)
+    next_oracle = libc.random()
+    assert rc == 0 and h.obj == eo and (h.succ == es).all() and moves > 0
+    assert next_host == next_oracle
 
 
 @pytest.mark.parametrize("name,gens", [("berlin52", 40), ("pr299", 12)])

@@ -191,6 +191,17 @@ struct tsp_dev_tours {
     void (*cl_post)(void *ctx, hipStream_t s, const int *d_err) = nullptr;
     void *cl_post_ctx = nullptr;
     bool cl_post_ran = false;
+    // ... and FURTHER runs of the same kind queued behind it without a wait in between (K iterations of tabu() per wait for the
+    // device): cl_chain(ctx, s, k, &iter, &tenure) queues what precedes launch k >= 1 (a re-arm that a stop word on the device
+    // can veto) and says with which iter / tenure it runs, or returns false when the chain ends; after launch k the run calls
+    // cl_post_k(ctx, s, k, d_err).  cl_chain_launched = launches queued in all (1 + the chained ones).
+    bool (*cl_chain)(void *ctx, hipStream_t s, int k, int *iter, int *tenure) = nullptr;
+    void (*cl_post_k)(void *ctx, hipStream_t s, int k, const int *d_err) = nullptr;
+    int cl_chain_launched = 0;
+    // device words of a chain: [0] stop (set by a post kernel: every later launch of the chain is a no-op), [2..3] the incumbent's
+    // cost (double), then per launch 8 ints of result + 1 double of cost
+    int *d_chain = nullptr;
+    int *h_chain = nullptr;          // pinned mirror
     bool h_state_fresh = false;   // h_state holds what d_state holds (set by a CLUSTER run's last poll, cleared by whatever queues work after it)
     int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)

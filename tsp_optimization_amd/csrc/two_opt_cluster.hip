@@ -1850,6 +1850,26 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         if (e == hipSuccess && launches_done == 0 && t->cl_post) {   // a driver's follow-up, decided on the device (see tsp_dev_tours::cl_post)
             t->cl_post(t->cl_post_ctx, s, a.err);
             t->cl_post = nullptr; t->cl_post_ran = true;
+            // the driver's next iterations, queued behind this one without a wait (tsp_dev_tours::cl_chain): the same kernel on
+            // the tour the follow-up leaves, with the epochs running on; a stop word on the device turns the launches that
+            // follow a failed iteration into no-ops (their re-arm is vetoed, the control block says `done`)
+            t->cl_chain_launched = 1;
+            if (t->cl_chain && max_steps < 0 && !fs_avail) {
+                for (int k = 1; e == hipSuccess && t->cl_chain(t->cl_post_ctx, s, k, &a.iter, &a.tenure); ++k) {
+                    if ((unsigned long long)t->cl_epoch + (unsigned)a.max_iters + 6ull >= 0xffffffffull) {
+                        TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
+                        t->cl_epoch = 0;
+                    }
+                    a.epoch0 = t->cl_epoch;
+                    t->cl_epoch += ((unsigned)a.max_iters + 5u) & ~1u;
+                    TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, p, a); });
+                    if (e != hipSuccess) break;
+                    if (t->cl_post_k) t->cl_post_k(t->cl_post_ctx, s, k, a.err);
+                    t->cl_chain_launched = k + 1;
+                }
+                if (e != hipSuccess) { (void)hipGetLastError(); e = hipSuccess; }   // the chain simply ends here: the iterations queued so far stand
+            }
+            t->cl_chain = nullptr; t->cl_post_k = nullptr;
         }
         if (e != hipSuccess) {
             // the attribute or the launch was refused (an LDS size this device does not grant): nothing ran, the tours in

@@ -145,6 +145,47 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_post(const TourState *st
     tabu_kick_body(order, pos, stamp, n, a, b, iter, tenure, result, list, list_n, list_cap);
 }
 
+// ---- K iterations of tabu() per wait for the device ------------------------------------------------------------------------
+// The same tail for launch k of a chain of iterations queued without a wait in between (tsp_dev_tours::cl_chain).  chain[0] is
+// the stop word: once an iteration could not be completed on the device -- its descent did not finish in its launch, the
+// exchange gave up, or the kick's trial was rejected (the host must draw again) -- every later launch of the chain is a no-op:
+// the re-arm in front of it is vetoed and the control block says `done`.  The incumbent's cost lives in chain[2..3] (double).
+// res = {accepted, a1, b1, 0, ran, improved, why-not (1 descent unfinished / give-up), 0, cost (double)}.
+__global__ void k_rearm_chain(TourState *states, const int *chain, int first_chunk) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || chain[0]) return;
+    TourState *st = states;
+    st->ci = 0; st->cj = 0; st->chunk_rows = first_chunk; st->done = 0;
+    st->seen_cost = st->obj;
+    st->parity = 0; st->pending = 0;
+}
+__global__ __launch_bounds__(kApplyThreads) void k_tabu_post_chain(TourState *state, const int *err, int *order, int *pos, int *stamp, int n,
+                                                                   int a, int b, int iter, int tenure, int *chain, int k, int2 *list,
+                                                                   int *list_n, int list_cap, int *snap) {
+    __shared__ int s_go, s_better;
+    const int tid = threadIdx.x;
+    int *res = chain + 4 + 10 * k;
+    if (tid == 0) {
+        double *best = reinterpret_cast<double *>(chain + 2);
+        int go = 0, better = 0, why = 0;
+        if (!chain[0]) {
+            go = state->done && !(err && *err);
+            if (!go) { why = 1; chain[0] = 1; state->done = 1; }   // the host finishes this iteration its own way
+            else if (state->obj < *best) { better = 1; *best = state->obj; }
+        }
+        s_go = go; s_better = better;
+        res[0] = 0; res[1] = 0; res[2] = 0; res[3] = 0; res[4] = go; res[5] = better; res[6] = why; res[7] = 0;
+        *reinterpret_cast<double *>(res + 8) = go ? state->obj : 0.0;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    if (s_better) {
+        for (int p = tid; p < n; p += kApplyThreads) snap[p] = order[p];
+        __syncthreads();
+    }
+    tabu_kick_body(order, pos, stamp, n, a, b, iter, tenure, res, list, list_n, list_cap);
+    if (tid == 0 && !res[0]) chain[0] = 1;   // rejected: the host draws the next trial (tabusearch.c:262-287); done stays set
+}
+
 // HEU_VNS's kick (src/vns.c:11-100) on tour 0: with tour[] the walk from node 0, positions p1 < p2 < p3 (host draws),
 // the new tour is tour[0..p1] tour[p2+1..p3] tour[p1+1..p2] tour[p3+1..n-1] (:60-62: a->d, e->b, c->f; the reference reads
 // tour[n] for f when p3 == n-1, here the walk closes on tour[0]).  Out of place into the second copy, node 0 at position 0.
@@ -713,6 +754,115 @@ int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int 
     return status;
 }
 
+// `count` iterations of tabu() (src/tabusearch.c:238-309) in ONE wait for the device: the CLUSTER engine's launches of iterations
+// iter0 .. iter0 + count - 1 are queued back to back, each followed by k_tabu_post_chain (incumbent + the kick's first trial with
+// the host-drawn ab[2k], ab[2k + 1]), each preceded by a re-arm that the chain's stop word can veto.  *completed = iterations that
+// ran to their kick's trial; the last of them may have had its trial rejected (*last_accepted = 0: the host draws further
+// trials, tsp_dev_tours_tabu_kick, before it goes on), and an iteration whose descent did not finish in its launch is not counted:
+// the host runs it through tsp_dev_tours_tabu_iteration.  Returns 0 with *completed = 0 when the chain does not apply (another
+// engine, a long list): nothing was touched.
+int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab, double time_limit_s,
+                             double *best_obj, double *obj, int *improved, int *completed, int *last_accepted) {
+    constexpr int kMaxChain = 64;
+    if (!t || !tabu || t->B != 1 || tabu->inst != t->inst || !best_obj || !tenure || !ab || !completed || count < 1) return TSP_DEV_E_ARG;
+    *completed = 0;
+    if (last_accepted) *last_accepted = 0;
+    count = std::min(count, kMaxChain);
+    for (int k = 0; k < count; ++k)
+        if (ab[2 * k] < 0 || ab[2 * k] >= t->n || ab[2 * k + 1] < 0 || ab[2 * k + 1] >= t->n || tenure[k] < 0) return TSP_DEV_E_ARG;
+    if (iter0 < 0) return TSP_DEV_E_ARG;
+    // the chain rides on the CLUSTER engine's tabu variant: the conditions of tsp_tabu_run's first branch, and room in the list
+    // of non-zero stamps for the two entries every accepted kick appends (no scan, no compaction inside a chain)
+    if (TSP_SW(t->inst, TABU_DENSE, 0) != 0 || TSP_SW(t->inst, ENGINE, 0) == 1 || !tsp_cluster_fits(t, TSP_2OPT_BEST) ||
+        !tsp_cluster_sorted(t, TSP_2OPT_BEST))
+        return TSP_OK;
+    {
+        tsp_dev_ctx *cx = t->inst->ctx;
+        if (TSP_SW(t->inst, ENGINE, 0) != 3 && cx->cl_skip > 0) return TSP_OK;   // after a give-up: the single-iteration path counts the back-off down
+    }
+    t->cl_tabu_plan = true;
+    struct PlanGuard { tsp_dev_tours *t; ~PlanGuard() { t->cl_tabu_plan = false; } } plan_guard{t};
+    bool usable = false;
+    int rc = tabu_list_prepare(t, tabu, &usable);
+    if (rc) return rc;
+    if (!usable || tabu->list_ub + 2ll * count > std::min<long long>(kTabuListMax, tabu->list_cap) || tabu->list_ub + 2ll * count > tabu->list_compact_at)
+        return TSP_OK;
+    rc = kick_buffers(t);
+    if (rc) return rc;
+    hipStream_t s = t->inst->ctx->stream;
+    const size_t chain_ints = 4 + 10 * (size_t)kMaxChain;
+    if (!t->d_chain) {
+        TSP_HIP_TRY(hipMalloc(&t->d_chain, chain_ints * sizeof(int)));
+        TSP_HIP_TRY(hipHostMalloc(&t->h_chain, chain_ints * sizeof(int)));
+    }
+    if (!t->d_order_snap) TSP_HIP_TRY(hipMalloc(&t->d_order_snap, (size_t)t->n * sizeof(int)));
+    memset(t->h_chain, 0, chain_ints * sizeof(int));
+    memcpy(t->h_chain + 2, best_obj, sizeof(double));
+    TSP_HIP_TRY(hipMemcpyAsync(t->d_chain, t->h_chain, chain_ints * sizeof(int), hipMemcpyHostToDevice, s));
+    rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
+    if (rc) return rc;
+    TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+    struct Chain { tsp_dev_tours *t; tsp_dev_tabu *tabu; int iter0, count; const int *tenure, *ab; } ch{t, tabu, iter0, count, tenure, ab};
+    auto post = [](void *ctx, hipStream_t st, int k, const int *d_err) {
+        Chain *q = static_cast<Chain *>(ctx);
+        tsp_dev_tours *tt = q->t;
+        hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, st, tt->d_state, q->tabu->d_tabu_pairs);   // leaves the side words at zero
+        hipLaunchKernelGGL(k_tabu_post_chain, dim3(1), dim3(kApplyThreads), 0, st, tt->d_state, d_err, tt->d_order, tt->d_pos, q->tabu->d_stamp,
+                           tt->n, q->ab[2 * k], q->ab[2 * k + 1], q->iter0 + k, q->tenure[k], tt->d_chain, k, q->tabu->d_list, q->tabu->d_list_n,
+                           q->tabu->list_cap, tt->d_order_snap);
+    };
+    t->cl_post_ctx = &ch; t->cl_post_ran = false;
+    t->cl_post = [](void *ctx, hipStream_t st, const int *d_err) {
+        Chain *q = static_cast<Chain *>(ctx);
+        hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, st, q->t->d_state, q->tabu->d_tabu_pairs);
+        hipLaunchKernelGGL(k_tabu_post_chain, dim3(1), dim3(kApplyThreads), 0, st, q->t->d_state, d_err, q->t->d_order, q->t->d_pos, q->tabu->d_stamp,
+                           q->t->n, q->ab[0], q->ab[1], q->iter0, q->tenure[0], q->t->d_chain, 0, q->tabu->d_list, q->tabu->d_list_n,
+                           q->tabu->list_cap, q->t->d_order_snap);
+    };
+    t->cl_post_k = post;
+    t->cl_chain = [](void *ctx, hipStream_t st, int k, int *iter, int *ten) {
+        Chain *q = static_cast<Chain *>(ctx);
+        if (k >= q->count) return false;
+        const int chunk = std::min(q->t->first_min_rows, std::max(1, q->t->n - 1));
+        hipLaunchKernelGGL(k_rearm_chain, dim3(1), dim3(64), 0, st, q->t->d_state, q->t->d_chain, chunk);
+        *iter = q->iter0 + k; *ten = q->tenure[k];
+        return true;
+    };
+    int done = 0, fell = 0;
+    const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, &done, &fell, tabu, iter0, tenure[0]);
+    const bool post_ran = t->cl_post_ran;
+    const int launched = t->cl_chain_launched;
+    t->cl_post = nullptr; t->cl_post_k = nullptr; t->cl_chain = nullptr; t->cl_post_ctx = nullptr; t->cl_post_ran = false; t->cl_chain_launched = 0;
+    t->h_state_fresh = false;
+    if (!post_ran) return status < 0 && !fell ? status : TSP_OK;   // nothing was launched: the tour is as it was
+    // the results: one copy, one wait (the run's own wait came before the chain's last kernels were known to be through only if
+    // the chain was a single launch; the copy below is ordered behind all of them either way)
+    TSP_HIP_TRY(hipMemcpyAsync(t->h_chain, t->d_chain, chain_ints * sizeof(int), hipMemcpyDeviceToHost, s));
+    TSP_HIP_TRY(hipStreamSynchronize(s));
+    (void)hipGetLastError();
+    tabu->last_run_list = true;
+    int nc = 0;
+    for (int k = 0; k < launched && k < count; ++k) {
+        const int *res = t->h_chain + 4 + 10 * k;
+        if (!res[4]) break;
+        double c;
+        memcpy(&c, res + 8, sizeof c);
+        if (obj) obj[k] = c;
+        if (improved) improved[k] = res[5];
+        if (res[5]) t->h_obj_snap.assign(1, c);
+        if (res[0] && tabu->list_valid) {
+            tabu->list_ub += 2;
+            if (tabu->list_ub > tabu->list_cap) tabu->list_valid = false;
+        }
+        if (last_accepted) *last_accepted = res[0];
+        ++nc;
+    }
+    memcpy(best_obj, t->h_chain + 2, sizeof(double));
+    *completed = nc;
+    if (fell && nc == 0) return TSP_OK;   // the exchange gave up in the first launch: nothing completed, the host takes the other path
+    return status == TSP_TIME_LIMIT_EXCEEDED ? status : TSP_OK;
+}
+
 // alg_2opt_tabu on the resident tour 0 (no upload, no download): *obj = the recomputed cost (tabusearch.c:168-172)
 int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj) {
     if (!t || t->B != 1 || (tabu && tabu->inst != t->inst)) return TSP_DEV_E_ARG;
@@ -863,7 +1013,7 @@ void tsp_dev_tours_destroy(tsp_dev_tours *t) {
     (void)hipFree(t->d_row_ticket); (void)hipFree(t->d_row_evals); (void)hipFree(t->d_row_slot);
     (void)hipFree(t->d_pxy); (void)hipFree(t->d_pe); (void)hipFree(t->d_pid);
     (void)hipFree(t->d_cl_slots); (void)hipFree(t->d_cl_pairtab); (void)hipFree(t->d_cl_stats);
-    (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result); (void)hipHostFree(t->h_cl_err);
+    (void)hipFree(t->d_chain); (void)hipHostFree(t->h_chain); (void)hipFree(t->d_order_snap); (void)hipFree(t->d_kick_result); (void)hipHostFree(t->h_kick_result); (void)hipHostFree(t->h_cl_err);
     (void)hipHostFree(t->h_state);
     for (int m = 0; m < 2; ++m) if (t->graph_exec[m]) (void)hipGraphExecDestroy(t->graph_exec[m]);
     delete t;

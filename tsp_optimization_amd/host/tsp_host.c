@@ -20,7 +20,37 @@
 
 #include "tsp_hip.h"
 
+/* ---- the libc stream, looked ahead ----------------------------------------------------------------------------------------
+ * A chain of tabu() iterations (tsp_dev_tours_tabu_iterations) needs the kick's first draws of EVERY iteration before it is
+ * queued.  The values of the iterations that then do not run on the device (the chain stops at the first rejected kick) were
+ * drawn too early, not wrongly: they go back to the front of this window, and every draw of this file -- URAND(), rand_choice(),
+ * the skipped draws of a shard -- takes from the window before it calls random() again.  So the sequence of values the program
+ * consumes is the reference's, draw for draw. */
+#define AHEAD_CAP 256
+static long g_ahead[AHEAD_CAP];
+static int g_ahead_n = 0;   /* values waiting, oldest first */
+
+static long host_random(void) {
+    if (g_ahead_n > 0) {
+        const long v = g_ahead[0];
+        memmove(g_ahead, g_ahead + 1, sizeof(long) * (size_t)(--g_ahead_n));
+        return v;
+    }
+    return random();
+}
+static void host_random_unget(const long *v, int count) {   /* v[0] is the next value to be served */
+    if (count <= 0) return;
+    if (g_ahead_n + count > AHEAD_CAP) LOG_E("look-ahead window of the libc stream overflows");
+    memmove(g_ahead + count, g_ahead, sizeof(long) * (size_t)g_ahead_n);
+    memcpy(g_ahead, v, sizeof(long) * (size_t)count);
+    g_ahead_n += count;
+}
+int tsp_host_random_lookahead(void) { return g_ahead_n; }
+#undef URAND
+#define URAND() (((double)host_random()) / RAND_MAX)   /* include/utility.h:36 on the looked-ahead stream */
+
 #define GRASP_ITER_TIME_LIM 120 /* src/heuristics.c:11 */
+#define TABU_CHAIN 64           /* most iterations of tabu() queued per wait for the device */
 #define MULTISTART_BATCH 256    /* GRASP starts constructed per device call in HEU_Grasp_iter */
 
 /* ---- device context and instance cache -------------------------------------------------------- */
@@ -498,6 +528,21 @@ int HEU_VNS(instance *inst) { return tsp_host_vns(inst, -1); }
  * improves (:241-249), and the kick (:262-309) -- one tiny launch per trial that tests (a,a1) (b,b1) (a,b) (a1,b1) against
  * the tabu list with check_tenure's lazy clears, carries the 2-exchange out and stamps the removed edges; the host only
  * draws a and b and steps the tenure policy. */
+/* the tenure policies, applied after an iteration's kick (:298-304).  draw == 0: a dry run that predicts the tenures of a chain
+ * (step_policy :33-37 and linear_policy :47-59 draw nothing; random_policy :69-72 draws, and a chain never spans such a step) */
+static void tabu_policy_step(int policy, int iter, int *tenure, int *rising, int lo, int hi, int draw) {
+    if (policy == 0) {                                   /* step_policy :33-37 */
+        if (iter % 100 == 0) *tenure = (*tenure == lo) ? hi : lo;
+    } else if (policy == 1) {                            /* linear_policy :47-59 */
+        if (*tenure > hi) *tenure = hi;
+        if (*tenure < lo) *tenure = lo;
+        if (*tenure == hi || *tenure == lo) *rising = !*rising;
+        if (*rising) (*tenure)++; else (*tenure)--;
+    } else if (draw) {                                   /* random_policy :69-72 */
+        if (iter == 1 || iter % 100 == 0) *tenure = rand_choice(lo, hi + 1);
+    }
+}
+
 int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
     const int n = inst->num_nodes;
     struct timeval t0, t1;
@@ -519,37 +564,74 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
     int lo = (int)ceil(n * 0.02), hi = (int)round(n * 0.1);  /* :213-214, MIN/MAX_TENURE_RATE :12-13 */
     if (lo == hi) hi += 2; else if (hi < lo) { int tt = lo; lo = hi; hi = tt; }
     int tenure = lo, rising = 0;
-    for (int iter = 1; max_iterations < 0 || iter <= max_iterations; iter++) {
+    const char *chain_env = getenv("TSP_TABU_CHAIN");
+    const int chain_max = chain_env && *chain_env ? (atoi(chain_env) < 1 ? 1 : (atoi(chain_env) > 64 ? 64 : atoi(chain_env))) : TABU_CHAIN;
+    int iter = 1;
+    /* a chain stops at the first rejected kick, and the launches queued behind that point are wasted (no-ops, ~10 us each): the
+     * chain is made about twice as long as the chains have lately run (about one kick in four is rejected at n = 10 000 with 400
+     * live stamps, one in six at n = 299) */
+    double mean_run = 8.0;
+    while (max_iterations < 0 || iter <= max_iterations) {
         gettimeofday(&t1, 0);
         if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
-        double obj = 0.0;
-        int accepted = 0, improved = 0;
-        /* the first draws of the kick (:264-265) are made before the call: nothing else draws until then, and the call
-         * carries them to the device behind the run's last launches (one wait less per iteration) */
-        int a = rand_choice(0, n), b = rand_choice(0, n);
+        /* A chain of K iterations per wait for the device.  K ends where the host must act between two iterations: at the cap on
+         * the iterations, and -- random policy -- at an iteration whose policy step draws (:69-72: that draw comes after the
+         * iteration's kick draws, so the iteration is the chain's last).  Step and linear policies draw nothing: the tenure of
+         * every iteration of the chain is known now. */
+        int K = chain_env && *chain_env ? chain_max : (int)(2.0 * mean_run + 2.0);
+        if (K > chain_max) K = chain_max;
+        if (max_iterations >= 0 && K > max_iterations - iter + 1) K = (int)(max_iterations - iter + 1);
+        if (policy == 2)
+            for (int k = 0; k < K - 1; k++)
+                if (iter + k == 1 || (iter + k) % 100 == 0) { K = k + 1; break; }
+        int tenures[64], ab[128], improved[64];
+        long raw[128];
+        double objs[64];
+        {
+            int ten = tenure, ris = rising;
+            for (int k = 0; k < K; k++) {
+                tenures[k] = ten;
+                tabu_policy_step(policy, iter + k, &ten, &ris, lo, hi, 0);
+            }
+        }
+        /* the first draws of every iteration's kick (:264-265), in the order the iterations would make them */
+        for (int k = 0; k < 2 * K; k++) { raw[k] = host_random(); ab[k] = (int)((((double)raw[k]) / RAND_MAX) * n); }
+        int completed = 0, accepted = 0;
         pthread_mutex_lock(&g_lock);
-        rc = tsp_dev_tours_tabu_iteration(t, tb, iter, tenure, limit_of(inst), a, b, &best_obj, &obj, &improved, &accepted);   /* :238-249 */
+        rc = tsp_dev_tours_tabu_iterations(t, tb, iter, K, tenures, ab, limit_of(inst), &best_obj, objs, improved, &completed, &accepted);   /* :238-249, :262-309 */
         pthread_mutex_unlock(&g_lock);
-        if (improved) have_best = 1;
-        if (rc < 0) dev_fail("tsp_dev_tours_tabu_iteration", rc);
-        if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
-        while (!accepted) {                                  /* :262-287: draws until a pair of free, disjoint edges comes up */
-            a = rand_choice(0, n); b = rand_choice(0, n);
+        if (rc < 0) dev_fail("tsp_dev_tours_tabu_iterations", rc);
+        for (int k = 0; k < completed; k++) if (improved[k]) have_best = 1;   /* the incumbent is updated before the status is looked at (:241-249, :255) */
+        if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); host_random_unget(raw + 2 * completed, 2 * (K - completed)); break; }
+        if (completed == 0) {
+            /* the chain did not apply, or its first iteration could not be finished on the device: this iteration the one-wait
+             * way, with the draws it has; the later iterations' draws wait for their turn */
+            host_random_unget(raw + 2, 2 * (K - 1));
+            double obj = 0.0;
+            int imp = 0;
             pthread_mutex_lock(&g_lock);
-            rc = tsp_dev_tours_tabu_kick(t, tb, a, b, iter, tenure, &accepted);   /* + :288-290 move, :306-309 stamps */
+            rc = tsp_dev_tours_tabu_iteration(t, tb, iter, tenure, limit_of(inst), ab[0], ab[1], &best_obj, &obj, &imp, &accepted);
+            pthread_mutex_unlock(&g_lock);
+            if (imp) have_best = 1;
+            if (rc < 0) dev_fail("tsp_dev_tours_tabu_iteration", rc);
+            if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
+            completed = 1;
+        } else {
+            host_random_unget(raw + 2 * completed, 2 * (K - completed));
+        }
+        mean_run = 0.75 * mean_run + 0.25 * completed;
+        /* every completed iteration but the last had its kick accepted (the chain stops at a rejection) */
+        for (int k = 0; k < completed - 1; k++) tabu_policy_step(policy, iter + k, &tenure, &rising, lo, hi, 1);
+        const int last = iter + completed - 1;
+        while (!accepted) {                                  /* :262-287: draws until a pair of free, disjoint edges comes up */
+            const int a = rand_choice(0, n), b = rand_choice(0, n);
+            pthread_mutex_lock(&g_lock);
+            rc = tsp_dev_tours_tabu_kick(t, tb, a, b, last, tenure, &accepted);   /* + :288-290 move, :306-309 stamps */
             pthread_mutex_unlock(&g_lock);
             if (rc) dev_fail("tsp_dev_tours_tabu_kick", rc);
         }
-        if (policy == 0) {                                   /* step_policy :33-37 */
-            if (iter % 100 == 0) tenure = (tenure == lo) ? hi : lo;
-        } else if (policy == 1) {                            /* linear_policy :47-59 */
-            if (tenure > hi) tenure = hi;
-            if (tenure < lo) tenure = lo;
-            if (tenure == hi || tenure == lo) rising = !rising;
-            if (rising) tenure++; else tenure--;
-        } else {                                             /* random_policy :69-72 */
-            if (iter == 1 || iter % 100 == 0) tenure = rand_choice(lo, hi + 1);
-        }
+        tabu_policy_step(policy, last, &tenure, &rising, lo, hi, 1);
+        iter = last + 1;
     }
     pthread_mutex_lock(&g_lock);
     rc = have_best ? tsp_dev_tours_restore(t) : 0;
