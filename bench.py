@@ -64,6 +64,47 @@ def golden(name):
         return json.load(f)
 
 
+def host_lib():
+    """libtsp_host.so (the C host mirror: the reference's own function names on its `instance` struct) and the ctypes view of that
+    struct (include/tsp_host.h == the reference's include/utility.h:113-160)."""
+    import ctypes as C
+    from tsp_optimization_amd.build import lib_path
+    if "lib" not in host_lib.__dict__:
+        class _Edge(C.Structure):
+            _fields_ = [("i", C.c_int), ("j", C.c_int)]
+
+        class _Method(C.Structure):
+            _fields_ = [("id", C.c_int), ("edge_type", C.c_int), ("name", C.c_char_p), ("use_cplex", C.c_int)]
+
+        class _Params(C.Structure):
+            _fields_ = [("file_path", C.c_char_p), ("num_threads", C.c_int), ("time_limit", C.c_int), ("method", _Method), ("verbose", C.c_int),
+                        ("integer_cost", C.c_int), ("seed", C.c_int), ("perf_prof", C.c_int), ("callback_2opt", C.c_int)]
+
+        class _Solution(C.Structure):
+            _fields_ = [("obj_best", C.c_double), ("edges", C.POINTER(_Edge)), ("time_to_solve", C.c_double), ("xbest", C.POINTER(C.c_double))]
+
+        class _Instance(C.Structure):
+            _fields_ = [("params", _Params), ("name", C.c_char_p), ("comment", C.c_char_p), ("nodes", C.POINTER(C.c_double)), ("num_nodes", C.c_int),
+                        ("weight_type", C.c_int), ("num_columns", C.c_long), ("ind", C.POINTER(C.c_int)), ("thread_seeds", C.POINTER(C.c_uint)),
+                        ("solution", _Solution)]
+        host_lib.lib, host_lib.Instance, host_lib.Edge = C.CDLL(lib_path("libtsp_host.so")), _Instance, _Edge
+    return host_lib.lib, host_lib.Instance
+
+
+def host_instance(xy, wt, time_limit=-1):
+    """An `instance` whose nodes / edges point into numpy arrays the caller keeps alive -> (instance, edges [n, 2] int32)."""
+    import ctypes as C
+    _, _Instance = host_lib()
+    n = len(xy)
+    edges = np.zeros((n, 2), dtype=np.int32)
+    hi = _Instance()
+    hi.params.time_limit = time_limit; hi.params.integer_cost = 1; hi.params.seed = 123; hi.params.perf_prof = 1
+    hi.nodes = xy.ctypes.data_as(C.POINTER(C.c_double)); hi.num_nodes = n; hi.weight_type = wt
+    hi.num_columns = n * (n - 1) // 2
+    hi.solution.edges = edges.ctypes.data_as(C.POINTER(host_lib.Edge))
+    return hi, edges
+
+
 def sharded_configs(E, MS, ctx, rank, world, device, comm=None):
     """BASELINE configs[3] and [4] sharded k % world over the ranks: construct + 2-opt per rank, one all_reduce(MIN) of
     the packed (cost, start), one broadcast of the winner's tour; every rank checks the winner against the goldens.
@@ -123,34 +164,10 @@ def sharded_configs(E, MS, ctx, rank, world, device, comm=None):
     # libc stream, refines the ones k % world == rank on this rank's device and, with world > 1, runs the collective epilogue
     # (all-reduce(min) + broadcast over RCCL through the C ABI, failure agreement included) itself
     import ctypes as C
-    from tsp_optimization_amd.build import lib_path
-    H = C.CDLL(lib_path("libtsp_host.so"))
-
-    class _Edge(C.Structure):
-        _fields_ = [("i", C.c_int), ("j", C.c_int)]
-
-    class _Method(C.Structure):
-        _fields_ = [("id", C.c_int), ("edge_type", C.c_int), ("name", C.c_char_p), ("use_cplex", C.c_int)]
-
-    class _Params(C.Structure):
-        _fields_ = [("file_path", C.c_char_p), ("num_threads", C.c_int), ("time_limit", C.c_int), ("method", _Method), ("verbose", C.c_int),
-                    ("integer_cost", C.c_int), ("seed", C.c_int), ("perf_prof", C.c_int), ("callback_2opt", C.c_int)]
-
-    class _Solution(C.Structure):
-        _fields_ = [("obj_best", C.c_double), ("edges", C.POINTER(_Edge)), ("time_to_solve", C.c_double), ("xbest", C.POINTER(C.c_double))]
-
-    class _Instance(C.Structure):   # include/tsp_host.h == the reference's include/utility.h:147-160
-        _fields_ = [("params", _Params), ("name", C.c_char_p), ("comment", C.c_char_p), ("nodes", C.POINTER(C.c_double)), ("num_nodes", C.c_int),
-                    ("weight_type", C.c_int), ("num_columns", C.c_long), ("ind", C.POINTER(C.c_int)), ("thread_seeds", C.POINTER(C.c_uint)),
-                    ("solution", _Solution)]
+    H, _Instance = host_lib()
     xy5 = rand_instance(5000)
     n5, P5 = 5000, 128
-    edges = np.zeros((n5, 2), dtype=np.int32)
-    hi = _Instance()
-    hi.params.time_limit = -1; hi.params.integer_cost = 1; hi.params.seed = 123; hi.params.perf_prof = 1
-    hi.nodes = xy5.ctypes.data_as(C.POINTER(C.c_double)); hi.num_nodes = n5; hi.weight_type = E.EUC_2D
-    hi.num_columns = n5 * (n5 - 1) // 2
-    hi.solution.edges = edges.ctypes.data_as(C.POINTER(_Edge))
+    hi, edges = host_instance(xy5, E.EUC_2D)
     costs5 = np.full(P5, np.nan)
     succ5 = np.zeros((P5, n5), dtype=np.int32)
     st5 = (E.Stats * P5)()
@@ -746,52 +763,37 @@ def main():
         inst.reload_switches()
         res["four_stamp_reads_per_pair"]["hbm_frac"] = res["four_stamp_reads_per_pair"]["those_bytes_per_s_GBps"] / HBM_PEAK_GBS
         res["live_stamps"] = live
-        # iterations of tabu() (tabusearch.c:238-309) on resident state: alg_2opt_tabu + incumbent + kick per iteration, the way the C
-        # host's tsp_host_tabu drives them -- chains of 32 iterations per wait for the device (tsp_dev_tours_tabu_iterations), a chain
-        # stopping where a kick's first trial is rejected -- and, next to it, one iteration per wait (round 3's form)
-        def tabu_loop(chain):
-            tb = E.Tabu(inst)
-            tt = E.Tours(inst, 1)
-            tt.upload(s_t[0], o)                      # the local optimum reached above
-            krng = np.random.default_rng(11)
-            state = {"best": float("inf"), "it": 1, "waits": 0}
-            tenure = 200
+        # tabu() itself (tabusearch.c:188-320, step policy) through the C host: tsp_host_tabu of libtsp_host.so keeps tour, stamps and
+        # incumbent on the device, draws on the host's libc stream, and queues chains of iterations per wait for the device
+        # (tsp_dev_tours_tabu_iterations; a chain stops where a kick's first trial is rejected).  Rate = (run of 40 + N iterations
+        # minus run of 40 iterations): the initial HEU_2opt_greedy_iter (:200) cancels out.
+        import ctypes as C
+        H, _Instance = host_lib()
+        H.tsp_host_tabu.argtypes = [C.POINTER(_Instance), C.c_int, C.c_longlong]
 
-            def run(iters):
-                end = state["it"] + iters
-                while state["it"] < end:
-                    K = min(chain, end - state["it"])
-                    ab = krng.integers(0, N_NODES, size=(K, 2)).astype(np.int32)
-                    if K > 1:
-                        rc, done, acc, state["best"], _, _ = tt.tabu_iterations(tb, state["it"], [tenure] * K, ab, state["best"])
-                    else:
-                        done = 0
-                    if done == 0:
-                        rc, obj, state["best"], improved, acc = tt.tabu_iteration(tb, state["it"], tenure, int(ab[0, 0]), int(ab[0, 1]), state["best"])
-                        done = 1
-                    state["waits"] += 1
-                    last = state["it"] + done - 1
-                    while not acc:
-                        acc = tt.tabu_kick(tb, int(krng.integers(0, N_NODES)), int(krng.integers(0, N_NODES)), last, tenure)
-                    state["it"] = last + 1
-            run(40)
-            ctx.synchronize()
-            state["waits"] = 0
-            t1 = time.perf_counter()
-            run(iters)
-            ctx.synchronize()
-            dt = time.perf_counter() - t1
-            _, _, st_d = tt.download()
-            r = {"iterations": iters, "seconds": dt, "iterations_per_s": iters / dt, "tenure": tenure, "incumbent": state["best"],
-                 "list_entries": tb.list_info()[0], "worked_from_the_list": tb.list_info()[1], "waits_for_the_device": state["waits"],
-                 "sweeps_per_iteration": (st_d[0]["sweeps"]) / float(iters + 40)}
-            tb.close(); tt.close()
-            return r
-        iters = 400
-        res["tabu_iterations_on_resident_state"] = dict(tabu_loop(32), chain="32 iterations queued per wait (tsp_dev_tours_tabu_iterations)")
-        res["tabu_iterations_on_resident_state"]["one_iteration_per_wait"] = tabu_loop(1)
-        same = res["tabu_iterations_on_resident_state"]["incumbent"] == res["tabu_iterations_on_resident_state"]["one_iteration_per_wait"]["incumbent"]
-        res["tabu_iterations_on_resident_state"]["same_incumbent_both_ways"] = bool(same)
+        def tabu_rate(chain, iters):
+            if chain is None:
+                os.environ.pop("TSP_TABU_CHAIN", None)
+            else:
+                os.environ["TSP_TABU_CHAIN"] = str(chain)
+            dts, incumbent = [], None
+            for count in (40, 40 + iters):
+                hi, _edges = host_instance(xy, wt, time_limit=3600)
+                C.CDLL(None).srandom(123)
+                t1 = time.perf_counter()
+                H.tsp_host_tabu(C.byref(hi), 0, count)
+                dts.append(time.perf_counter() - t1)
+                incumbent = hi.solution.obj_best
+            os.environ.pop("TSP_TABU_CHAIN", None)
+            return {"iterations": iters, "seconds": dts[1] - dts[0], "iterations_per_s": iters / (dts[1] - dts[0]), "incumbent": incumbent}
+        iters = 600
+        chained = tabu_rate(None, iters)
+        single = tabu_rate(1, iters)
+        res["tabu_iterations_on_resident_state"] = dict(
+            chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123, chains of iterations queued per "
+                            "wait for the device (length adapted to how far the chains run)",
+            one_iteration_per_wait=single, same_incumbent_both_ways=bool(chained["incumbent"] == single["incumbent"]))
+        H.tsp_host_shutdown()
         out["alg_2opt_tabu_with_a_list"] = res
 
     if rank == 0 and world == 1 and not args.no_extras:

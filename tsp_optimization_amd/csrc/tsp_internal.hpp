@@ -58,7 +58,7 @@ constexpr int kApplyThreads = 1024;
     X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
     X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \
     X(CONSTRUCT_NN) X(LDS_PAIR) X(CLUSTER_FS_ROWS) X(CLUSTER_LPT) X(CLUSTER_B0) X(LDS_F32_MIN_N) X(CLUSTER_DEFER)          \
-    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN) X(EXH_PRIO)
+    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN) X(EXH_PRIO) X(CLUSTER_COOP)
 namespace tsp {
 enum SwitchId {
 #define TSP_SW_ENUM(name) SW_##name,

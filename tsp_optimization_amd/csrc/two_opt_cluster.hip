@@ -1536,7 +1536,29 @@ hipError_t cl_launch_k(tsp_dev_tours *t, const ClusterArgs &a, size_t lds) {
         if (e != hipSuccess) return e;
         granted = lds;
     }
-    hipLaunchKernelGGL(k, dim3(t->B * a.C), dim3(kClThreads), lds, s, a);
+    // Co-residency is asked for, not assumed: the exchange needs every workgroup of the launch on the chip at once.  The
+    // runtime's occupancy figure for THIS kernel variant with THIS much LDS (registers, LDS, waves: whatever limits it) times
+    // the CUs must cover the grid -- else the launch is refused here and the caller goes on with another engine, instead of
+    // finding out by the exchange's time-out.  (Asked once per variant, device and LDS size.)  What the figure cannot know -- a
+    // device shared with another process, CUs masked off -- remains the time-out's business (kClSpinMs).
+    static size_t occ_lds[64] = {0};
+    static int occ_blocks[64] = {0};
+    const int dv = t->inst->ctx->device & 63;
+    if (occ_lds[dv] != lds + 1) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, kClThreads, lds) != hipSuccess) { (void)hipGetLastError(); nb = 1; }
+        occ_blocks[dv] = nb; occ_lds[dv] = lds + 1;
+    }
+    const long long grid = (long long)t->B * a.C;
+    if (a.C > 1 && (long long)occ_blocks[dv] * std::max(1, t->inst->ctx->num_cus) < grid && !TSP_SW(t->inst, CLUSTER_ALLOW_OVERSUB, 0))
+        return hipErrorCooperativeLaunchTooLarge;
+    if (TSP_SW(t->inst, CLUSTER_COOP, 0) && a.C > 1) {   // measurement switch: the same grid as a cooperative launch (the runtime checks residency itself)
+        ClusterArgs copy = a;
+        void *args[] = {&copy};
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k), dim3((unsigned)grid), dim3(kClThreads), args, (unsigned)lds, s);
+        return e == hipSuccess ? hipGetLastError() : e;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kClThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1688,7 +1710,10 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
             // first to the least loaded workgroup (LPT), the others fill the tables up in turn.  Every pair is still tested in
             // every step; only who tests it changes.
             std::vector<int> order((size_t)n);
-            TSP_HIP_TRY(hipMemcpy(order.data(), t->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+            // on the engine's stream (created non-blocking: a null-stream copy is not ordered behind work queued on it -- a kick
+            // that was not waited for could still be rewriting the tour), then one wait
+            TSP_HIP_TRY(hipMemcpyAsync(order.data(), t->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+            TSP_HIP_TRY(hipStreamSynchronize(s));
             const double sc = (inst->wtype_public == TSP_ATT) ? 1.0 / sqrt(10.0) : 1.0;
             auto X = [&](int v) { return inst->h_xy[2 * (size_t)v]; };
             auto Y = [&](int v) { return inst->h_xy[2 * (size_t)v + 1]; };
@@ -1703,7 +1728,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
                     inc[v] = std::max(ds[v], len(v, pv));
                 }
                 std::vector<int> sperm((size_t)inst->n_slots);
-                TSP_HIP_TRY(hipMemcpy(sperm.data(), inst->d_sperm, sizeof(int) * sperm.size(), hipMemcpyDeviceToHost));
+                TSP_HIP_TRY(hipMemcpy(sperm.data(), inst->d_sperm, sizeof(int) * sperm.size(), hipMemcpyDeviceToHost));   // per-instance, written once at creation
                 for (int g = 0; g < ng; ++g)
                     for (int k = 0; k < 64; ++k) { const int v = sperm[(size_t)g * 64 + k]; if (v >= 0) gmx[g] = std::max(gmx[g], inc[v]); }
                 struct Item { double cost; int e; };

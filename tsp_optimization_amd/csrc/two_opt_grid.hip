@@ -149,18 +149,15 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_post(const TourState *st
 // The same tail for launch k of a chain of iterations queued without a wait in between (tsp_dev_tours::cl_chain).  chain[0] is
 // the stop word: once an iteration could not be completed on the device -- its descent did not finish in its launch, the
 // exchange gave up, or the kick's trial was rejected (the host must draw again) -- every later launch of the chain is a no-op:
-// the re-arm in front of it is vetoed and the control block says `done`.  The incumbent's cost lives in chain[2..3] (double).
+// nobody re-arms the control block, which says `done`.  The incumbent's cost lives in chain[2..3] (double).
 // res = {accepted, a1, b1, 0, ran, improved, why-not (1 descent unfinished / give-up), 0, cost (double)}.
-__global__ void k_rearm_chain(TourState *states, const int *chain, int first_chunk) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || chain[0]) return;
-    TourState *st = states;
-    st->ci = 0; st->cj = 0; st->chunk_rows = first_chunk; st->done = 0;
-    st->seen_cost = st->obj;
-    st->parity = 0; st->pending = 0;
-}
+// The kernel also does what k_tabu_fix_evals does after a run (the skipped pairs come off the evaluation count, the side words
+// go back to zero) and, when the iteration is complete and another one follows, the re-arm for it (k_rearm's stores): one
+// launch between two CLUSTER launches instead of three.
 __global__ __launch_bounds__(kApplyThreads) void k_tabu_post_chain(TourState *state, const int *err, int *order, int *pos, int *stamp, int n,
                                                                    int a, int b, int iter, int tenure, int *chain, int k, int2 *list,
-                                                                   int *list_n, int list_cap, int *snap) {
+                                                                   int *list_n, int list_cap, int *snap, unsigned long long *side,
+                                                                   int rearm_chunk /* > 0: another iteration follows */) {
     __shared__ int s_go, s_better;
     const int tid = threadIdx.x;
     int *res = chain + 4 + 10 * k;
@@ -168,6 +165,14 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_post_chain(TourState *st
         double *best = reinterpret_cast<double *>(chain + 2);
         int go = 0, better = 0, why = 0;
         if (!chain[0]) {
+            {   // k_tabu_fix_evals: read-and-zero as returning atomics (see there)
+                long long skipped = (long long)atomicExch(side, 0ull);
+                for (int p = 1; p <= 3; ++p) {
+                    const long long f = (long long)atomicExch(side + p, 0ull);
+                    skipped -= f * (f - 1) / 2;
+                }
+                state->evals -= skipped;
+            }
             go = state->done && !(err && *err);
             if (!go) { why = 1; chain[0] = 1; state->done = 1; }   // the host finishes this iteration its own way
             else if (state->obj < *best) { better = 1; *best = state->obj; }
@@ -183,7 +188,14 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_post_chain(TourState *st
         __syncthreads();
     }
     tabu_kick_body(order, pos, stamp, n, a, b, iter, tenure, res, list, list_n, list_cap);
-    if (tid == 0 && !res[0]) chain[0] = 1;   // rejected: the host draws the next trial (tabusearch.c:262-287); done stays set
+    if (tid == 0) {
+        if (!res[0]) chain[0] = 1;   // rejected: the host draws the next trial (tabusearch.c:262-287); done stays set
+        else if (rearm_chunk > 0) {  // the next iteration's alg_2opt_tabu starts on the kicked tour (k_rearm)
+            state->ci = 0; state->cj = 0; state->chunk_rows = rearm_chunk; state->done = 0;
+            state->seen_cost = state->obj;
+            state->parity = 0; state->pending = 0;
+        }
+    }
 }
 
 // HEU_VNS's kick (src/vns.c:11-100) on tour 0: with tour[] the walk from node 0, positions p1 < p2 < p3 (host draws),
@@ -803,29 +815,21 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     if (rc) return rc;
     TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
     struct Chain { tsp_dev_tours *t; tsp_dev_tabu *tabu; int iter0, count; const int *tenure, *ab; } ch{t, tabu, iter0, count, tenure, ab};
-    auto post = [](void *ctx, hipStream_t st, int k, const int *d_err) {
+    auto post = [](void *ctx, hipStream_t st, int k, const int *d_err) {   // ONE launch between two CLUSTER launches: evaluation count, incumbent, kick, re-arm
         Chain *q = static_cast<Chain *>(ctx);
         tsp_dev_tours *tt = q->t;
-        hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, st, tt->d_state, q->tabu->d_tabu_pairs);   // leaves the side words at zero
+        const int chunk = k + 1 < q->count ? std::min(tt->first_min_rows, std::max(1, tt->n - 1)) : 0;
         hipLaunchKernelGGL(k_tabu_post_chain, dim3(1), dim3(kApplyThreads), 0, st, tt->d_state, d_err, tt->d_order, tt->d_pos, q->tabu->d_stamp,
                            tt->n, q->ab[2 * k], q->ab[2 * k + 1], q->iter0 + k, q->tenure[k], tt->d_chain, k, q->tabu->d_list, q->tabu->d_list_n,
-                           q->tabu->list_cap, tt->d_order_snap);
+                           q->tabu->list_cap, tt->d_order_snap, q->tabu->d_tabu_pairs, chunk);
     };
     t->cl_post_ctx = &ch; t->cl_post_ran = false;
-    t->cl_post = [](void *ctx, hipStream_t st, const int *d_err) {
-        Chain *q = static_cast<Chain *>(ctx);
-        hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, st, q->t->d_state, q->tabu->d_tabu_pairs);
-        hipLaunchKernelGGL(k_tabu_post_chain, dim3(1), dim3(kApplyThreads), 0, st, q->t->d_state, d_err, q->t->d_order, q->t->d_pos, q->tabu->d_stamp,
-                           q->t->n, q->ab[0], q->ab[1], q->iter0, q->tenure[0], q->t->d_chain, 0, q->tabu->d_list, q->tabu->d_list_n,
-                           q->tabu->list_cap, q->t->d_order_snap);
-    };
     t->cl_post_k = post;
-    t->cl_chain = [](void *ctx, hipStream_t st, int k, int *iter, int *ten) {
+    t->cl_post = [](void *ctx, hipStream_t st, const int *d_err) { static_cast<Chain *>(ctx)->t->cl_post_k(ctx, st, 0, d_err); };
+    t->cl_chain = [](void *ctx, hipStream_t, int k, int *iter, int *ten) {
         Chain *q = static_cast<Chain *>(ctx);
         if (k >= q->count) return false;
-        const int chunk = std::min(q->t->first_min_rows, std::max(1, q->t->n - 1));
-        hipLaunchKernelGGL(k_rearm_chain, dim3(1), dim3(64), 0, st, q->t->d_state, q->t->d_chain, chunk);
-        *iter = q->iter0 + k; *ten = q->tenure[k];
+        *iter = q->iter0 + k; *ten = q->tenure[k];   // (the re-arm was the previous post kernel's last act, unless it stopped the chain)
         return true;
     };
     int done = 0, fell = 0;

@@ -568,9 +568,10 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
     const int chain_max = chain_env && *chain_env ? (atoi(chain_env) < 1 ? 1 : (atoi(chain_env) > 64 ? 64 : atoi(chain_env))) : TABU_CHAIN;
     int iter = 1;
     /* a chain stops at the first rejected kick, and the launches queued behind that point are wasted (no-ops, ~10 us each): the
-     * chain is made about twice as long as the chains have lately run (about one kick in four is rejected at n = 10 000 with 400
-     * live stamps, one in six at n = 299) */
+     * chain is made one and a half times as long as the chains have lately run (rand10000, step policy: one first trial in
+     * twelve is rejected, chains run ten iterations on average; one in six at n = 299) */
     double mean_run = 8.0;
+    long long st_chains = 0, st_queued = 0, st_done = 0, st_single = 0, st_retrials = 0;   /* TSP_HOST_STATS=1: printed at the end */
     while (max_iterations < 0 || iter <= max_iterations) {
         gettimeofday(&t1, 0);
         if (inst->params.time_limit > 0 && get_elapsed_time(t0, t1) > inst->params.time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
@@ -578,7 +579,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
          * the iterations, and -- random policy -- at an iteration whose policy step draws (:69-72: that draw comes after the
          * iteration's kick draws, so the iteration is the chain's last).  Step and linear policies draw nothing: the tenure of
          * every iteration of the chain is known now. */
-        int K = chain_env && *chain_env ? chain_max : (int)(2.0 * mean_run + 2.0);
+        int K = chain_env && *chain_env ? chain_max : (int)(1.5 * mean_run + 2.0);
         if (K > chain_max) K = chain_max;
         if (max_iterations >= 0 && K > max_iterations - iter + 1) K = (int)(max_iterations - iter + 1);
         if (policy == 2)
@@ -601,6 +602,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         rc = tsp_dev_tours_tabu_iterations(t, tb, iter, K, tenures, ab, limit_of(inst), &best_obj, objs, improved, &completed, &accepted);   /* :238-249, :262-309 */
         pthread_mutex_unlock(&g_lock);
         if (rc < 0) dev_fail("tsp_dev_tours_tabu_iterations", rc);
+        st_chains++; st_queued += K; st_done += completed;
         for (int k = 0; k < completed; k++) if (improved[k]) have_best = 1;   /* the incumbent is updated before the status is looked at (:241-249, :255) */
         if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); host_random_unget(raw + 2 * completed, 2 * (K - completed)); break; }
         if (completed == 0) {
@@ -615,7 +617,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
             if (imp) have_best = 1;
             if (rc < 0) dev_fail("tsp_dev_tours_tabu_iteration", rc);
             if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
-            completed = 1;
+            completed = 1; st_single++;
         } else {
             host_random_unget(raw + 2 * completed, 2 * (K - completed));
         }
@@ -628,11 +630,15 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
             pthread_mutex_lock(&g_lock);
             rc = tsp_dev_tours_tabu_kick(t, tb, a, b, last, tenure, &accepted);   /* + :288-290 move, :306-309 stamps */
             pthread_mutex_unlock(&g_lock);
+            st_retrials++;
             if (rc) dev_fail("tsp_dev_tours_tabu_kick", rc);
         }
         tabu_policy_step(policy, last, &tenure, &rising, lo, hi, 1);
         iter = last + 1;
     }
+    if (getenv("TSP_HOST_STATS"))
+        fprintf(stderr, "[tabu] %d iterations: %lld chains, %lld iterations queued, %lld completed in chains, %lld run singly, %lld further kick trials\n",
+                iter - 1, st_chains, st_queued, st_done, st_single, st_retrials);
     pthread_mutex_lock(&g_lock);
     rc = have_best ? tsp_dev_tours_restore(t) : 0;
     pthread_mutex_unlock(&g_lock);
