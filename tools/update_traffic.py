@@ -20,6 +20,23 @@ def mean_us(name, kernel):
 
 path = os.path.join(P, "roofline_traffic.json")
 d = json.load(open(path))
+if tag >= "r04":
+    # round 4: bench.py's timed kernels are the exhaustive sweep's (k_move_pos + k_exh, one pair per sweep)
+    KE, KM = "void k_exh<6, true, 4>", "void k_move_pos<6, true>"
+    fe, we = pmc("pmc_FETCH_SIZE", KE, "FETCH_SIZE"), pmc("pmc_WRITE_SIZE", KE, "WRITE_SIZE")
+    fm, wm = pmc("pmc_FETCH_SIZE", KM, "FETCH_SIZE"), pmc("pmc_WRITE_SIZE", KM, "WRITE_SIZE")
+    total = int(round((2 * fe + we + 2 * fm + wm) * 1024))
+    d["%s_exhaustive_sweep_n10000_hbm_bytes_per_launch" % tag] = total
+    d["%s_derivation" % tag] = {
+        "kernels": {"tsp::k_exh<6 (EUC_2D integer-coordinate variant), true, RJ = 4>": {"FETCH_SIZE_KiB_mean": fe, "WRITE_SIZE_KiB_mean": we},
+                    "tsp::k_move_pos<6, true>": {"FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm}},
+        "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per kernel, summed: one launch pair = one sweep = 49 985 000 delta expressions (raw sum = %d bytes)" % int(round((fe + we + fm + wm) * 1024)),
+        "algorithmic_operand_bytes_per_launch": 72 * 49985000,
+        "note": "the sweep's operands stay on chip: k_move_pos rewrites the 0.3 MB of position-ordered arrays, k_exh reads them once per wave (columns) and through the scalar cache (rows); HBM traffic is 0.1 % of SURVEY 8(d)'s 72 B per delta -- the kernel is VALU-bound",
+        "source": ["profiles/%s_pmc_FETCH_SIZE.json" % tag, "profiles/%s_pmc_WRITE_SIZE.json" % tag, "profiles/%s_kernel_stats.csv" % tag]}
+    json.dump(d, open(path, "w"), indent=1)
+    print(tag, "exhaustive sweep bytes per launch", total)
+    sys.exit(0)
 f, w = pmc("pmc_FETCH_SIZE", BEST, "FETCH_SIZE"), pmc("pmc_WRITE_SIZE", BEST, "WRITE_SIZE")
 sweeps = 1428
 total = int(round((2 * f + w) * 1024))
