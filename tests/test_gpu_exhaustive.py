@@ -58,7 +58,7 @@ def test_exhaustive_descents_equal_the_oracle_at_strip_boundaries(eng, ctx, monk
     _check(eng, ctx, monkeypatch, xy, O.EUC_2D, random_tour(n, rng))
 
 
-@pytest.mark.parametrize("rj,waves", [("1", "1"), ("1", "8"), ("2", "2"), ("4", "1"), ("4", "4"), ("4", "8"), ("8", "2"), ("8", "4")])
+@pytest.mark.parametrize("rj,waves", [("1", "1"), ("1", "8"), ("2", "2"), ("4", "1"), ("4", "4"), ("4", "8"), ("8", "2"), ("8", "4"), ("16", "1"), ("16", "2")])
 def test_exhaustive_descents_for_every_shape_of_the_grid(eng, ctx, monkeypatch, rj, waves):
     """Columns per lane (strip width 63 / 127 / 255) and waves per SIMD (how the row units are dealt) change no decision."""
     for n, seed in ((300, 1), (1000, 2)):

@@ -62,3 +62,9 @@ if dump and os.path.exists(dump):
     for v in cus.values():
         cc[v] += 1
     print("  CUs by number of waves:", dict(sorted(cc.items())), "(%d CUs seen)" % len(cus))
+    # does a workgroup's age on its CU follow its index?  mean time out of the rows per quarter of the grid, and per wave of the workgroup
+    rows = [ln.split() for ln in open(dump)]
+    nw = len(rows)
+    for part in range(4):
+        sel = [float(r[2]) for r in rows if int(r[0]) * 4 // nw == part]
+        print("    workgroups %d/4 of the grid: mean out of rows at %.1f us (min %.1f, max %.1f)" % (part + 1, sum(sel) / len(sel), min(sel), max(sel)))

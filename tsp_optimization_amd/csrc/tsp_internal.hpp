@@ -163,6 +163,9 @@ struct tsp_dev_tours {
     // exhaustive sweep in position order (two_opt_exh.hpp): the tour's coordinates, edge lengths and ids by position (padded)
     double2 *d_pxy = nullptr;
     int *d_pe = nullptr, *d_pid = nullptr;
+    bool exh_lds_granted = false;
+    int exh_share[4] = {0, 0, 0, 0};   // k_exh: rows per wave of each part of the grid (0: equal shares)
+    int exh_gens = 0;                  // ... parts (= workgroups per CU)
     int exh_lds = 0;                 // k_exh: dynamic LDS a workgroup asks for (unused; it pins the number of workgroups per CU)
     int exh_blocks = 0, exh_rj = 4, exh_prio = 1;  // k_exh: workgroups per tour (0: the tiled k_step executes the exhaustive sweep), columns per lane
     int *d_pairtab = nullptr;        // group pairs per cluster of k_sweep blocks (host-built), or nullptr

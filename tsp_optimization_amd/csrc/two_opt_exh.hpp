@@ -51,7 +51,7 @@ __device__ unsigned long long g_exh_w[8192 * 4];
 __device__ unsigned long long g_exh_t[8];
 #endif
 
-constexpr int kExhPad = 1024;          // positions past n that k_move_pos fills (>= the widest strip + 2)
+constexpr int kExhPad = 1152;          // positions past n that k_move_pos fills (>= the widest strip + 2)
 constexpr int kExhCluster = 32;        // blocks per first-level arrival counter
 constexpr int kRowBatch = 4;           // rows whose operands one scalar load instruction fetches
 
@@ -76,6 +76,31 @@ __device__ __forceinline__ int exh_dist(double cx, double cy, double rx, double 
         const double e = __builtin_fma(-10.0 * k, k, s);
         return __double2int_rz(k) + (e > 0.0 ? 1 : 0);
     }
+}
+
+// The same for the RJ columns of a lane against one row, STAGE BY STAGE across the columns: the wave issues in order, so the RJ
+// dependent chains (sub -> mul -> fma -> sqrt -> add -> floor -> fma -> compare -> convert -> add-with-carry) only overlap if
+// their instructions are interleaved in the stream.  Left to itself the scheduler keeps most of a chain together (fewer live
+// registers) and a lone wave then runs the chains one after the other (RJ = 16, one wave per SIMD: 2 960 cycles per row step
+// against 1 056 of issue).  The scheduling barriers pin the stage order.
+template <int WT, int RJ>
+__device__ __forceinline__ void exh_dist_row(const double (&cx)[RJ], const double (&cy)[RJ], double rx, double ry, int (&D)[RJ]) {
+    double s[RJ], k[RJ], e[RJ];
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) { const double dx = cx[q] - rx, dy = cy[q] - ry; s[q] = __builtin_fma(dx, dx, dy * dy); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) k[q] = __builtin_amdgcn_sqrt(WT == WT_ATT_ICOORD ? s[q] * 0.1 : s[q]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) k[q] = floor(k[q] + (WT == WT_EUC_2D_ICOORD ? 0.25 : 0.75));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) e[q] = __builtin_fma(WT == WT_ATT_ICOORD ? -10.0 * k[q] : -k[q], k[q], s[q]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RJ; ++q) D[q] = __double2int_rz(k[q]) + ((WT == WT_EUC_2D_ICOORD ? e[q] > k[q] : e[q] > 0.0) ? 1 : 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // (1) the pending move, out of place; (2) the tour AFTER that move in position order: coordinates, edge lengths, ids.
@@ -108,9 +133,11 @@ __global__ __launch_bounds__(kScanThreads) void k_move_pos(const double2 *__rest
     pid[pbase + k] = u;
 }
 
+// (RJ = 8 is built for three waves per SIMD: 170 VGPRs; RJ = 16 is meant for one or two waves per SIMD -- many independent
+// distances per wave instead of many waves)
 template <int WT, bool INT, int RJ>
-__global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const double2 *__restrict__ pxy_all, const int *__restrict__ pe_all,
-                                                      const int *__restrict__ pid_all, int waves_total, int prio_on) {
+__global__ __launch_bounds__(kScanThreads, (RJ == 8 ? 3 : 1)) void k_exh(const StepArgs a, const double2 *__restrict__ pxy_all, const int *__restrict__ pe_all,
+                                                      const int *__restrict__ pid_all, int waves_total, int prio_on, int4 share, int gens) {
     // the position arrays are kernel arguments of their own, restrict-qualified: the row operands are wave-uniform loads, and
     // the compiler only issues them as scalar loads (s_load: no vector-memory slot, no VGPRs) when it can prove that the
     // kernel's own stores and atomics (candidate slots, tickets) never touch them
@@ -134,8 +161,22 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const do
     const int strips = (n + WEFF - 1) / WEFF;                       // pair-columns 0 .. n-1
     long long total = 0;
     for (int s = 0; s < strips; ++s) total += min(n - 1, s * WEFF + WEFF - 1);   // pair-rows p' < q' <= Q0 + WEFF - 1, p' <= n - 2
-    const long long per = (total + waves_total - 1) / waves_total;
-    long long u_lo = per * gw, u_hi = min(total, u_lo + per);
+    // A SIMD serves its oldest wave first, and the workgroups of a CU are as old as their place in the grid: the first quarter of
+    // the grid leaves its rows at 13.7 us, the others at 20.6 / 28.2 / 35.4 (equal shares; tools/diag_exh.py) -- while four waves
+    // are active the SIMD's issue slots go 53 / 26 / 13 / 8 %.  share = the rows per wave of each part of the grid (quarters at four workgroups per CU) in those
+    // proportions (host: tsp_dev_tours_create), so that the four waves of a SIMD finish together; share.x == 0: equal shares.
+    long long per = (total + waves_total - 1) / waves_total;
+    long long u_lo = per * gw;
+    if (share.x > 0 && gens > 0) {   // gens = workgroups per CU = equal parts of the grid with a share of their own (2 .. 4)
+        const int wq = waves_total / gens, g = min(gens - 1, gw / wq), idx = gw - g * wq;
+        const int sh[4] = {share.x, share.y, share.z, share.w};
+        u_lo = 0;
+        for (int q = 0; q < g; ++q) u_lo += (long long)sh[q] * wq;
+        per = sh[g];
+        u_lo += per * idx;
+    }
+    long long u_hi = min(total, u_lo + per);
+    u_lo = min(u_lo, total);
 
     int bd = -1, bp = -1, bq = -1;     // integer costs: delta < 0  <=>  delta <= -1; (bd, no pair) loses every tie
     int wbd = -1;                      // wave-uniform: the lowest delta any lane of this wave has seen
@@ -191,8 +232,7 @@ __global__ __launch_bounds__(kScanThreads) void k_exh(const StepArgs a, const do
 #else
             const double2 r = r_in;
 #endif
-#pragma unroll
-            for (int k = 0; k < RJ; ++k) D[k] = exh_dist<WT>(cx[k], cy[k], r.x, r.y);
+            exh_dist_row<WT, RJ>(cx, cy, r.x, r.y, D);
             // lane 0's first column has no left neighbour in this wave (the DPP hands it 0): its pair belongs to the strip on
             // the left; should D alone ever pass the test below, the bookkeeping drops it (valid == false)
             sum[0] = __builtin_amdgcn_update_dpp(0, S[RJ - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, true) + D[0];

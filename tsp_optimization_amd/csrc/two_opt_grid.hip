@@ -344,10 +344,16 @@ int launch_step(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int te
             a.flat_slots = t->exh_blocks;
             const int wt_ = t->exh_blocks * (kScanThreads / 64);
             const dim3 g(t->exh_blocks, 1, t->B);
-            if (t->exh_rj == 8) hipLaunchKernelGGL((k_exh<WT, INT, 8>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
-            else if (t->exh_rj == 2) hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
-            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
-            else hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio);
+            if (t->exh_lds > 65536 - 1024 && !t->exh_lds_granted) {   // one workgroup per CU: more than half of the CU's LDS
+                const void *f = t->exh_rj == 16 ? reinterpret_cast<const void *>(k_exh<WT, INT, 16>) : (t->exh_rj == 8 ? reinterpret_cast<const void *>(k_exh<WT, INT, 8>) : reinterpret_cast<const void *>(k_exh<WT, INT, 4>));
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, t->exh_lds) != hipSuccess) { (void)hipGetLastError(); t->exh_lds = 65536 - 1024; }
+                t->exh_lds_granted = true;
+            }
+            if (t->exh_rj == 16) hipLaunchKernelGGL((k_exh<WT, INT, 16>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio, make_int4(t->exh_share[0], t->exh_share[1], t->exh_share[2], t->exh_share[3]), t->exh_gens);
+            else if (t->exh_rj == 8) hipLaunchKernelGGL((k_exh<WT, INT, 8>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio, make_int4(t->exh_share[0], t->exh_share[1], t->exh_share[2], t->exh_share[3]), t->exh_gens);
+            else if (t->exh_rj == 2) hipLaunchKernelGGL((k_exh<WT, INT, 2>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio, make_int4(t->exh_share[0], t->exh_share[1], t->exh_share[2], t->exh_share[3]), t->exh_gens);
+            else if (t->exh_rj == 1) hipLaunchKernelGGL((k_exh<WT, INT, 1>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio, make_int4(t->exh_share[0], t->exh_share[1], t->exh_share[2], t->exh_share[3]), t->exh_gens);
+            else hipLaunchKernelGGL((k_exh<WT, INT, 4>), g, dim3(kScanThreads), (size_t)t->exh_lds, s, a, t->d_pxy, t->d_pe, t->d_pid, wt_, t->exh_prio, make_int4(t->exh_share[0], t->exh_share[1], t->exh_share[2], t->exh_share[3]), t->exh_gens);
             return TSP_OK;
         }
     }
@@ -973,15 +979,42 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
         // VALU-bound and the waves' shares are equal, so a CU that the dispatcher handed six workgroups finishes 1.5 x later than
         // the mean (measured: waves leaving their rows between 13 and 40 us, mean 24.6).  Each workgroup therefore asks for
         // 1 / waves of the CU's LDS (it uses none of it): one more does not fit.
-        if (B == 1 && inst->ctx->lds_bytes >= 65536 && TSP_SW(inst, EXH_EVEN, 1)) t->exh_lds = std::min(65536, inst->ctx->lds_bytes / waves) - 1024;
+        if (B == 1 && inst->ctx->lds_bytes >= 65536 && TSP_SW(inst, EXH_EVEN, 1))
+            t->exh_lds = (waves == 1 ? (inst->ctx->lds_bytes * 3) / 5 : std::min(65536, inst->ctx->lds_bytes / waves)) - 1024;   // one per CU: more than half of it
         const int rj = TSP_SW(inst, EXH_RJ, 4);
-        t->exh_prio = TSP_SW(inst, EXH_PRIO, 1);
-        t->exh_rj = (rj == 8 || rj == 2 || rj == 1) ? rj : 4;
+        t->exh_prio = TSP_SW(inst, EXH_PRIO, 0);
+        t->exh_rj = (rj == 16 || rj == 8 || rj == 2 || rj == 1) ? rj : 4;
         t->partial_per_tour = std::max(t->partial_per_tour, (size_t)t->exh_blocks);
         const size_t pn = (size_t)B * (inst->n + kExhPad);
         TSP_HIP_TRY(hipMalloc(&t->d_pxy, pn * sizeof(double2)));
         TSP_HIP_TRY(hipMalloc(&t->d_pe, pn * sizeof(int)));
         TSP_HIP_TRY(hipMalloc(&t->d_pid, pn * sizeof(int)));
+        {   // rows per wave for each of the `waves` equal parts of the grid (k_exh: the older a workgroup, the larger its share);
+            // TSP_EXH_SHARES = per-cent figures (or "0": equal shares), defaults measured on MI355X for 2 / 3 / 4 workgroups per CU
+            t->exh_share[0] = t->exh_share[1] = t->exh_share[2] = t->exh_share[3] = 0;
+            t->exh_gens = 0;
+            int pc[4] = {0, 0, 0, 0};
+            bool on = B == 1 && waves >= 2 && waves <= 4;
+            if (waves == 4) { pc[0] = 53; pc[1] = 26; pc[2] = 13; pc[3] = 8; }
+            if (waves == 3) { pc[0] = 56; pc[1] = 29; pc[2] = 15; }
+            if (waves == 2) { pc[0] = 62; pc[1] = 38; }
+            const char *e = getenv("TSP_EXH_SHARES");
+            if (e && *e) {
+                pc[0] = pc[1] = pc[2] = pc[3] = 0;
+                const int got = sscanf(e, "%d,%d,%d,%d", &pc[0], &pc[1], &pc[2], &pc[3]);
+                on = on && got == waves && pc[0] > 0;
+            }
+            const int W = 64 * t->exh_rj, WEFF = W - 1, strips = (inst->n + WEFF - 1) / WEFF;
+            long long total = 0;
+            for (int sidx = 0; sidx < strips; ++sidx) total += std::min(inst->n - 1, sidx * WEFF + WEFF - 1);
+            const long long wtot = (long long)t->exh_blocks * (kScanThreads / 64);
+            const int sum = pc[0] + pc[1] + pc[2] + pc[3];
+            if (on && sum > 0 && wtot % waves == 0) {
+                const long long wq = wtot / waves;
+                t->exh_gens = waves;
+                for (int q = 0; q < waves; ++q) t->exh_share[q] = (int)std::max<long long>(1, (total * pc[q] + sum * wq - 1) / (sum * wq));
+            }
+        }
     }
     TSP_HIP_TRY(hipMalloc(&t->d_cl_ticket, cl_words * sizeof(int)));
     TSP_HIP_TRY(hipMemset(t->d_cl_ticket, 0, cl_words * sizeof(int)));   // every launch leaves them at zero
