@@ -811,7 +811,8 @@ def main():
                 "config4_att532_256_starts": [2.9, 2.9, 2.9, 2.4],
                 "config5_rand5000_128_individuals": [190, 183, 154, 145],
                 "engine": ["LDS (1 workgroup per tour)", "CLUSTER (4 per tour)", "CLUSTER (8)", "CLUSTER (16)"],
-                "source": "tools/pop_time.py, tools/shard_time.py (DESIGN.md section 5): 1.31 x on 8 GPUs for configs[4], 1.2 x for configs[3]"}}
+                "source": "tools/pop_time.py, tools/shard_time.py (DESIGN.md section 5): 1.31 x on 8 GPUs for configs[4], 1.2 x for configs[3]; "
+                          "configs[4] runs through the C host (HEU_2opt_population_multistart), configs[3] through the Python launcher on the C communicator"}}
         out["all_checks_ok"] = bool(out.get("parity", {}).get("final_tour_matches_golden", True) and
                                     all(v for d in out["other_configs"].values() for k, v in d.items()
                                         if k.startswith(("winner_", "every_"))))

@@ -67,6 +67,16 @@ def test_exhaustive_descents_for_every_shape_of_the_grid(eng, ctx, monkeypatch, 
         _check(eng, ctx, monkeypatch, xy, O.EUC_2D, succ0, {"TSP_EXH_RJ": rj, "TSP_EXH_WAVES": waves})
 
 
+@pytest.mark.parametrize("shares", ["0", "70,20,7,3", "10,20,30,40", "97,1,1,1"])
+def test_exhaustive_descent_whatever_share_of_the_rows_a_workgroup_gets(eng, ctx, monkeypatch, shares):
+    """The rows are dealt to the workgroups by their age on the CU (TSP_EXH_SHARES, a performance choice): any split, however
+    lopsided, must leave every pair evaluated exactly once."""
+    for n, seed in ((777, 3), (2000, 4)):
+        xy = rand_instance(n, seed=seed, hi=50000)
+        _, succ0, _ = O.greedy(xy, O.EUC_2D)
+        _check(eng, ctx, monkeypatch, xy, O.EUC_2D, succ0, {"TSP_EXH_SHARES": shares})
+
+
 @pytest.mark.parametrize("name,wt", [("att532", O.ATT), ("pr299", O.EUC_2D), ("rand600", O.CEIL_2D), ("berlin52", O.EUC_2D), ("rat575", O.CEIL_2D)])
 def test_exhaustive_descents_on_the_three_integer_root_metrics(eng, ctx, monkeypatch, name, wt):
     xy, _ = load_instance(name)
