@@ -212,6 +212,9 @@ int tsp_host_genetic_gpus(instance *inst, long long max_generations, double two_
  * of iterations and needs every iteration's first kick draws up front; what a chain leaves unconsumed is served first by every
  * later draw of this library: URAND() of this build, rand_choice()).  0 whenever a capped run (max_iterations) has returned. */
 int tsp_host_random_lookahead(void);
+/* Seconds the last tsp_host_tabu / tsp_host_vns call of this thread spent in its iteration loop (the initial
+ * HEU_2opt_greedy_iter excluded): iterations / this = the driver's rate. */
+double tsp_host_last_driver_loop_seconds(void);
 /* Counters of the last alg_2opt / alg_2opt_tabu call of this thread. */
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms);
 /* Releases the cached device context / instances (optional; also done at exit). */

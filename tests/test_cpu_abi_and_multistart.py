@@ -48,7 +48,7 @@ def test_libtsp_host_exports_the_reference_entry_points(built):
               "export_tour", "fitness_batch", "HEU_2opt_grasp_multistart", "tsp_host_multistart_gpus", "tsp_host_multistart_shard",
               "HEU_2opt_population_multistart", "tsp_host_population_gpus", "tsp_host_population_shard",
               "tsp_host_multistart_epilogue", "tsp_host_multistart_last_error", "tsp_host_set_collectives",
-              "tsp_host_rccl_id_file_state", "tsp_host_last_grasp_iter_starts", "tsp_host_random_lookahead", "tsp_host_genetic_gpus", "tsp_host_genetic_ex",
+              "tsp_host_rccl_id_file_state", "tsp_host_last_grasp_iter_starts", "tsp_host_random_lookahead", "tsp_host_last_driver_loop_seconds", "tsp_host_genetic_gpus", "tsp_host_genetic_ex",
               "tsp_host_vns", "tsp_host_tabu", "HEU_VNS", "HEU_Tabu_step", "HEU_Tabu_lin", "HEU_Tabu_rand", "HEU_Genetic",
               "HEU_extramileage", "HEU_2opt_extramileage", "kick",
               "tsp_host_last_stats", "tsp_host_shutdown"]:

@@ -83,6 +83,7 @@ static void tabu_cache_drop(void) {
 
 static unsigned long g_clock = 0;
 static __thread long long t_sweeps, t_evals, t_moves, t_grasp_iter_starts;
+static __thread double t_driver_loop_s;   /* seconds the last tsp_host_tabu / tsp_host_vns spent in its iteration loop (not the initial solution) */
 static __thread double t_device_ms;
 
 static void dev_fail(const char *what, int rc) {
@@ -161,6 +162,7 @@ void tsp_host_shutdown(void) {
 }
 
 long long tsp_host_last_grasp_iter_starts(void) { return t_grasp_iter_starts; }
+double tsp_host_last_driver_loop_seconds(void) { return t_driver_loop_s; }
 
 void tsp_host_last_stats(long long *sweeps, long long *evals, long long *moves, double *device_ms) {
     if (sweeps) *sweeps = t_sweeps;
@@ -489,6 +491,8 @@ int tsp_host_vns(instance *inst, long long max_rounds) {
     pthread_mutex_unlock(&g_lock);
     if (rc) dev_fail("tsp_host_vns: resident tour", rc);
     long long rounds = 0;
+    struct timeval tl0, tl1;
+    gettimeofday(&tl0, 0);
     for (long long round = 0; max_rounds < 0 || round < max_rounds; round++, rounds++) {
         gettimeofday(&t1, 0);
         if (get_elapsed_time(t0, t1) > time_limit) { status = TIME_LIMIT_EXCEEDED; break; }
@@ -506,6 +510,8 @@ int tsp_host_vns(instance *inst, long long max_rounds) {
         if (rc) dev_fail("tsp_host_vns: round", rc);
         if (inst->params.verbose >= 3 && obj == best_obj) LOG_I("Updated incumbent: %0.0f", best_obj);
     }
+    gettimeofday(&tl1, 0);
+    t_driver_loop_s = get_elapsed_time(tl0, tl1);
     pthread_mutex_lock(&g_lock);
     rc = tsp_dev_tours_restore(t);
     pthread_mutex_unlock(&g_lock);
@@ -571,6 +577,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
      * chain is made one and a half times as long as the chains have lately run (rand10000, step policy: one first trial in
      * twelve is rejected, chains run ten iterations on average; one in six at n = 299) */
     double mean_run = 8.0;
+    struct timeval tl0, tl1;
+    gettimeofday(&tl0, 0);
     long long st_chains = 0, st_queued = 0, st_done = 0, st_single = 0, st_retrials = 0;   /* TSP_HOST_STATS=1: printed at the end */
     while (max_iterations < 0 || iter <= max_iterations) {
         gettimeofday(&t1, 0);
@@ -636,6 +644,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         tabu_policy_step(policy, last, &tenure, &rising, lo, hi, 1);
         iter = last + 1;
     }
+    gettimeofday(&tl1, 0);
+    t_driver_loop_s = get_elapsed_time(tl0, tl1);
     if (getenv("TSP_HOST_STATS"))
         fprintf(stderr, "[tabu] %d iterations: %lld chains, %lld iterations queued, %lld completed in chains, %lld run singly, %lld further kick trials\n",
                 iter - 1, st_chains, st_queued, st_done, st_single, st_retrials);
