@@ -420,12 +420,15 @@ def test_sorted_scan_on_256_workgroups_equals_the_grid_engine_at_mid_sizes(eng, 
     inst.close()
 
 
-def test_chain_of_tabu_iterations_equals_the_iterations_one_by_one(eng, ctx):
-    """tsp_dev_tours_tabu_iterations: K iterations of tabu() queued back to back (one wait for the device) against the same K
+@pytest.mark.parametrize("in_kernel", [1, 0])
+def test_chain_of_tabu_iterations_equals_the_iterations_one_by_one(eng, ctx, in_kernel, monkeypatch):
+    """tsp_dev_tours_tabu_iterations: K iterations of tabu() inside one launch (in_kernel, the default) or queued back to back
+    (TSP_TABU_INKERNEL=0) -- one wait for the device either way -- against the same K
     iterations through tsp_dev_tours_tabu_iteration, on two handles that start alike: same costs, same incumbent, same tour,
     same stamps.  A chain stops at the first iteration whose kick is rejected (here forced: a == b) -- the iterations behind it
     must not have run (tour and stamps as after the one-by-one replay up to that point), and the caller's next kick finishes
     the iteration."""
+    monkeypatch.setenv("TSP_TABU_INKERNEL", str(in_kernel))   # (switches are read when the instance handle is made)
     xy, wt = load_instance("pr1002")
     n = len(xy)
     inst = eng.Instance(ctx, xy, wt, 1)
@@ -464,9 +467,11 @@ def test_chain_of_tabu_iterations_equals_the_iterations_one_by_one(eng, ctx):
         assert rc == 0 and acc
     rc, done, last_acc, best2, obj2, imp2 = t2.tabu_iterations(tb2, 9, tenures[8:], rest, best2)
     assert rc == 0 and done == K - 8 and last_acc and best2 == best
-    sa, oa, _ = t1.download()
-    sb, ob, _ = t2.download()
+    sa, oa, sta = t1.download()
+    sb, ob, stb = t2.download()
     assert (sa[0] == sb[0]).all() and oa[0] == ob[0] and (tb1.download() == tb2.download()).all()
+    for key in ("sweeps", "evals", "moves", "reversed"):   # the reference-equivalent counters: the skipped pairs come off once per launch or once per iteration
+        assert sta[0][key] == stb[0][key], key
     # the incumbents kept on the device are the same tour
     t1.restore(); t2.restore()
     assert (t1.download()[0][0] == t2.download()[0][0]).all()

@@ -390,3 +390,15 @@ def test_alg_2opt_from_four_threads_on_private_copies(host):
         _, es, eo, _, _ = O.two_opt_first(base.xy, base.wt, starts[k][0], starts[k][1])
         assert results[k] is not None and (results[k][0] == es).all() and results[k][1] == eo, k
         host.free_instance(C.byref(copies[k]))
+
+
+def test_first_device_use_leaves_the_libc_random_stream_alone():
+    """The HIP runtime reseeds libc's random() while it initialises.  tabu() and HEU_VNS seed in main (the reference: solver.c) and
+    do device work (HEU_2opt_greedy_iter) before their first draw: a FRESH process must still get the values its seed promises
+    (tsp_dev_open parks the generator on a scratch state while the runtime comes up; tools/rng_probe.py is the check)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rng_probe.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("after ")]
+    assert len(lines) == 2 and all("stream intact" in l for l in lines), out.stdout

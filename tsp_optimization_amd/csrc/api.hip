@@ -1,6 +1,8 @@
 // api.hip -- context / instance handles and the host-tour entry points of include/tsp_hip.h.
 #include "tsp_internal.hpp"
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <time.h>
 
@@ -184,8 +186,23 @@ int tsp_dev_count(void) {
     return c;
 }
 
+namespace {
+// The HIP runtime's initialisation reseeds libc's random() generator (tools/rng_probe.py: srandom(123), a first device call,
+// random() -> not the value the seed promises, and a different one in every process).  The reference's drivers seed once in
+// main and draw with random() / rand() throughout (utility.h:36), and tabu() / HEU_VNS begin with device work here
+// (HEU_2opt_greedy_iter) before their first draw: the process's generator is parked on a scratch state while the runtime comes
+// up and put back exactly as the caller left it.
+struct LibcRandomKeeper {
+    char scratch[256];
+    char *old;
+    LibcRandomKeeper() { old = initstate(1u, scratch, sizeof scratch); }
+    ~LibcRandomKeeper() { if (old) (void)setstate(old); }
+};
+}  // namespace
+
 int tsp_dev_open(int device, tsp_dev_ctx **out) {
     if (!out) return TSP_DEV_E_ARG;
+    LibcRandomKeeper keep_libc_random;
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0 || device < 0 || device >= count) {
@@ -206,6 +223,14 @@ int tsp_dev_open(int device, tsp_dev_ctx **out) {
             c->lds_bytes = optin;
     }
     TSP_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {   // the rest of what a process's first device work sets up (allocator, a first copy on the stream), still under the keeper
+        void *w = nullptr;
+        int zero = 0;
+        TSP_HIP_TRY(hipMalloc(&w, 256));
+        TSP_HIP_TRY(hipMemcpyAsync(w, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+        TSP_HIP_TRY(hipStreamSynchronize(c->stream));
+        TSP_HIP_TRY(hipFree(w));
+    }
     guard.c = nullptr;
     *out = c;
     return TSP_OK;

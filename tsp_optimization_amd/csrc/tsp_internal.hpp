@@ -58,7 +58,7 @@ constexpr int kApplyThreads = 1024;
     X(SWEEP_BLOCKS) X(SWEEP_TABLE) X(BEST_ROWS_PER_BLOCK) X(BEST_RECS) X(FIRST_V1) X(FIRST_GRID_ROWS) X(FIRST_RJ)          \
     X(FIRST_MIN_ROWS) X(FIRST_MAX_ROWS) X(FIRST_ROWS_PER_BLOCK) X(COUNT_EVALS) X(USE_GRAPH) X(CONSTRUCT_GLOBAL)            \
     X(CONSTRUCT_NN) X(LDS_PAIR) X(CLUSTER_FS_ROWS) X(CLUSTER_LPT) X(CLUSTER_B0) X(LDS_F32_MIN_N) X(CLUSTER_DEFER)          \
-    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN) X(EXH_PRIO) X(CLUSTER_COOP)
+    X(EXH_POS) X(EXH_WAVES) X(EXH_RJ) X(EXH_EVEN) X(EXH_PRIO) X(CLUSTER_COOP) X(TABU_INKERNEL)
 namespace tsp {
 enum SwitchId {
 #define TSP_SW_ENUM(name) SW_##name,
@@ -205,6 +205,10 @@ struct tsp_dev_tours {
     // cost (double), then per launch 8 ints of result + 1 double of cost
     int *d_chain = nullptr;
     int *h_chain = nullptr;          // pinned mirror
+    // ... or INSIDE one launch (TSP_TABU_INKERNEL, the default): the kernel runs cl_ik_n iterations with the kick's first trials
+    // d_chain + cl_ik_par = {a, b, tenure} per iteration, keeps the incumbent in d_order_snap and writes the same result words
+    int cl_ik_n = 0;
+    int cl_ik_par = 0;
     bool h_state_fresh = false;   // h_state holds what d_state holds (set by a CLUSTER run's last poll, cleared by whatever queues work after it)
     int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)

@@ -60,6 +60,7 @@ using gi32c = __attribute__((address_space(1))) int;
 __device__ unsigned long long g_cl_prof[256][8];
 __device__ unsigned long long g_cl_wstat[256][4];   // per workgroup of tour 0: lane pairs, tier-1 pairs, delta expressions, staged records
 __device__ unsigned long long g_cl_b0[8];   // sweeps with a winner, sum of -b0, sum of -delta of the winner, sweeps with b0 == delta, with b0 >= delta / 2, >= delta / 1.25
+__device__ unsigned long long g_cl_tail[256][12];   // per workgroup of tour 0, tails of tabu() iterations inside a launch: ticks {cost + wait, decision (first workgroup), release, exchange, acquire, kick, -, tails; per sweep: the list's side effects (thread 64), the first workgroup's read of the live-edge count, the exchange proper}
 __device__ unsigned long long g_cl_cnt[8];   // sorted scan, all workgroups: units, live rows, row quads, tier-1 blocks, tier-2 pairs, survivors
 #define CL_T(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); prof[k] += t_ - tprev; tprev = t_; } } while (0)
 #else
@@ -89,6 +90,13 @@ struct ClusterArgs {
     const int *tabu_list_n;
     int tabu_list_cap, iter, tenure;
     unsigned long long *tabu_side;
+    // iterations of tabu() inside the launch (TABU variant; chain_n == 0: one descent, as ever): chain = {stop word, next iteration
+    // of the chain, the incumbent's cost (double), 10 result words per iteration}, chain_par = {a, b, tenure, a and b inside the replica} per
+    // iteration (the kick's first trial, host-drawn), snap = the incumbent's tour (nodes by position)
+    int *chain;
+    const int *chain_par;
+    int chain_n;
+    int *snap;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int defer_moves;        // carry the swaps of a move out during the next step's exchange (TSP_CLUSTER_DEFER)
     int use_b0;             // BEST, sorted scan: start every sweep from the bound the previous exchange yields (TSP_CLUSTER_B0)
@@ -498,6 +506,17 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     if (st->done) return;
     int *order_g = a.orders + (size_t)tour * n;
     gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * kClCopies * C * kClSlotGranules;
+    // the iteration of tabu() this launch is at (its number and tenure decide what is tabu): a launch that carries a chain of
+    // iterations goes on where the launch before it stopped (chain[1])
+    int cur_iter = a.iter, cur_ten = a.tenure, ck = 0;
+    double inc_best = 0.0;
+    if constexpr (TABU) {
+        if (a.chain_n > 0) {
+            ck = a.chain[1];
+            cur_iter = a.iter + ck; cur_ten = a.chain_par[5 * ck + 2];
+            inc_best = *reinterpret_cast<const double *>(a.chain + 2);
+        }
+    }
 
     // the replica: eight loads per thread in flight at a time (a launch loads 120 KB per workgroup at n = 10 000; one load per
     // thread and trip was ~40 dependent memory latencies -- most of the fixed cost of a short resident run)
@@ -580,6 +599,17 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         __syncthreads();
     }
 
+    // iterations of tabu() inside the launch, integer costs: the tour's cost is kept by every workgroup from move to move and kick
+    // to kick (integer terms: the sum is exact in any order and equals the reference's recomputation, tabusearch.c:168-172)
+    double run_obj = 0.0;
+    if constexpr (TABU && INT) {
+        if (a.chain_n > 0) {
+            double cc = 0.0;
+            for (int v = tid; v < n; v += kClThreads) cc += cl_node<WT, INT, CT>(coord, order, pos, n, v).ds;
+            run_obj = block_sum<double>(cc, s_d);
+            __syncthreads();
+        }
+    }
     const double prune2 = 2.0 * a.prune;   // doubled: keeps ties (a lane does not meet its pairs in key order)
     bool failed = false;
     // the workgroup's share of the group-pair table never changes: when it fits one round of box tests (one entry per
@@ -667,6 +697,33 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             __syncthreads();
         }
     };
+    // the group bounds of the four nodes whose incident edges the 2-exchange (wi, wj) changes, from the tour BEFORE the swaps with
+    // those four edges patched (see the move below); waves 1 .. 4, one group each
+    auto patch_bounds = [&](int wi, int wj, int pa, int pb) {
+        const int a1 = (int)order[pa + 1 == n ? 0 : pa + 1], b1 = (int)order[pb + 1 == n ? 0 : pb + 1];
+        if (wave >= 1 && wave <= 4) {   // (wave 0 computes the next sweep's bound meanwhile)
+            const int g = wave == 1 ? (wi >> 6) : (wave == 2 ? (wj >> 6) : (wave == 3 ? (a1 >> 6) : (b1 >> 6)));
+            const int v = g * 64 + lane;
+            double m = 0.0;
+            if (v < n) {
+                const int p = (int)pos[v];
+                int su = (int)order[p + 1 == n ? 0 : p + 1], pr = (int)order[p == 0 ? n - 1 : p - 1];
+                if (v == wi) su = wj;            // a -> b
+                else if (v == wj) su = wi;       // b's old successor b1 gives way to a
+                if (v == a1) pr = b1;            // a1's old predecessor a gives way to b1
+                else if (v == b1) pr = a1;       // b1's old predecessor b gives way to a1
+                m = fmax(cl_dist<WT, INT, CT>(coord, v, su), cl_dist<WT, INT, CT>(coord, v, pr));
+            }
+            m = cl_wave_max_nonneg(m);
+            if (lane == 0) gmax[g] = m;
+        }
+    };
+    // tabu lists: the first list entry this thread accounts for in every sweep, and its ids inside the replica (see the side effects)
+    int2 tl_e = make_int2(0, 0);
+    int tl_iu = 0, tl_iv = 0;
+    bool tl_have = false;
+    int tl_m = 0;   // entries of the list (the count runs on past the capacity, as on the host): read once, kept up with the kicks of a chain
+    if constexpr (TABU) tl_m = *a.tabu_list_n;
     bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
     for (int iter = 0; iter < a.max_iters && !done && !failed && !leave; ++iter) {
         int row_lo = 0, row_hi = n - 1;
@@ -909,10 +966,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                                                 const bool lo = gi < gj;
                                                 const int i = lo ? gi : gj, jn = lo ? gj : gi;
                                                 const int a1 = a.gid[lo ? ri.succ : rj.succ], b1 = a.gid[lo ? rj.succ : ri.succ];
-                                                is_tabu = stamp_is_tabu(a.tabu + udir_pos(i, jn, n), a.iter, a.tenure) ||
-                                                          stamp_is_tabu(a.tabu + udir_pos(i, a1, n), a.iter, a.tenure) ||
-                                                          stamp_is_tabu(a.tabu + udir_pos(jn, b1, n), a.iter, a.tenure) ||
-                                                          stamp_is_tabu(a.tabu + udir_pos(i, b1, n), a.iter, a.tenure);
+                                                is_tabu = stamp_is_tabu(a.tabu + udir_pos(i, jn, n), cur_iter, cur_ten) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(i, a1, n), cur_iter, cur_ten) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(jn, b1, n), cur_iter, cur_ten) ||
+                                                          stamp_is_tabu(a.tabu + udir_pos(i, b1, n), cur_iter, cur_ten);
                                             }
                                             if (!is_tabu) {
                                                 bd = delta; key = kk;
@@ -1169,7 +1226,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (owners) wip = (unsigned)__builtin_amdgcn_readlane((int)ip, __builtin_ctzll(owners));
             ClCand cd{d, k2, wip};
             bool okx = true;
+#ifdef TSP_STAMPS
+            const unsigned long long tx0 = wall_clock64();
+#endif
             if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, cd, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
+#ifdef TSP_STAMPS
+            if (tid == 0 && tour == 0 && c < 256) g_cl_tail[c][10] += wall_clock64() - tx0;
+#endif
             if (lane == 0) { *s_win_d = cd.d; *s_win_k = cd.key; *s_win_ip = cd.ipair; *s_fail = okx ? 0 : 1; }
 #ifdef TSP_STAMPS
             if constexpr (SORTED && BEST) {
@@ -1195,16 +1258,48 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 // node ids).  The move of this sweep is applied after the barrier that follows.
                 auto nsucc = [&](int v) { int p2 = (int)pos[a.iid[v]] + 1; if (p2 == n) p2 = 0; return a.gid[(int)order[p2]]; };
                 auto npred = [&](int v) { int p2 = (int)pos[a.iid[v]]; p2 = p2 == 0 ? n - 1 : p2 - 1; return a.gid[(int)order[p2]]; };
-                auto live_v = [&](int sv) { return sv != 0 && !(a.iter - sv > a.tenure); };
+                auto live_v = [&](int sv) { return sv != 0 && !(cur_iter - sv > cur_ten); };
                 auto live = [&](int x, int y) { return live_v(a.tabu[udir_pos(x, y, n)]); };
-                const int m = min(*a.tabu_list_n, a.tabu_list_cap);
-                for (int k = c * (kClThreads - 64) + tid - 64; k < m; k += C * (kClThreads - 64)) {
-                    const int2 e = a.tabu_list[k];
+#ifdef TSP_STAMPS
+                const unsigned long long ts0 = wall_clock64();
+#endif
+                const int m = min(tl_m, a.tabu_list_cap);
+                // The entries go round the workgroups 1 .. C - 1, one per thread: the first workgroup, which reads the live-edge count
+                // and (in a chain of iterations) decides the kicks, is the one the cluster waits for in every sweep -- its exchange
+                // shares the CU's memory path with whatever its other waves load (rand10000: 137.6 -> 131.3 us per iteration)
+                const bool spread = C > 1 && !(a.dbg & 64);
+                const int kstep = spread ? (C - 1) * (kClThreads - 64) : C * (kClThreads - 64);
+                const int k0 = spread ? (c == 0 ? m : (c - 1) + (C - 1) * (tid - 64)) : c * (kClThreads - 64) + tid - 64;
+                for (int k = k0; k < m; k += kstep) {
+                    // An entry is a chain of dependent reads -- the entry, its stamp, the node maps, the neighbours' stamps -- and the
+                    // whole cluster waits for the longest one (this loop, not the exchange beside it, was 7 of a sweep's 10 us
+                    // with a list of a few hundred live stamps).  So: a thread keeps its first entry, that entry's ids inside the
+                    // replica in registers from sweep to sweep (a list only grows inside a launch: entries never move), the
+                    // entry's stamp and the ids of its four tour neighbours are fetched together, and then all six stamps the
+                    // accounting can ask for (live() has no side effect: reading one the reference's && chain would not have
+                    // reached changes nothing) -- two round trips to memory instead of six to eight.  What is left of them costs
+                    // 1.5 us of a sweep (the workgroup that publishes last has only the rest of the exchange to hide its entry
+                    // behind).  Measured and not kept: the entry's last contribution remembered with the neighbours it was
+                    // computed from (no load at all in most sweeps: +6 us per iteration); the first round trip issued before
+                    // the scan (+3 us: every wait for a load in the scan then waits for it too); the first workgroup left out of
+                    // the group-pair table (no difference).
+                    const bool mine = k == k0;
+                    int2 e;
+                    int iu, iv;
+                    if (mine && tl_have) { e = tl_e; iu = tl_iu; iv = tl_iv; }
+                    else {
+                        e = a.tabu_list[k];
+                        iu = a.iid[e.x]; iv = a.iid[e.y];
+                        if (mine) { tl_e = e; tl_iu = iu; tl_iv = iv; tl_have = true; }
+                    }
                     const int u = e.x, v = e.y;
                     int *sp = a.tabu + udir_pos(u, v, n);
+                    const int pu = (int)pos[iu], pv = (int)pos[iv];
+                    const int su_i = (int)order[pu + 1 == n ? 0 : pu + 1], s2_i = (int)order[pv + 1 == n ? 0 : pv + 1];
+                    const int pru_i = (int)order[pu == 0 ? n - 1 : pu - 1], prv_i = (int)order[pv == 0 ? n - 1 : pv - 1];
                     const int sv = *sp;
+                    const int su = a.gid[su_i], s2 = a.gid[s2_i], pru = a.gid[pru_i], prv = a.gid[prv_i];
                     if (sv == 0) continue;
-                    const int su = nsucc(u), s2 = nsucc(v);
                     const bool uv = su == v, vu = s2 == u;
                     if (!live_v(sv)) {
                         if (!uv && !vu) *sp = 0;
@@ -1219,25 +1314,35 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         }
                         continue;
                     }
+                    // the stamps of (u, succ u), (v, succ v) and, per orientation, (aa, pred w), (pred w, w): fetched together
+                    const int s_usu = a.tabu[udir_pos(u, su, n)], s_vs2 = a.tabu[udir_pos(v, s2, n)];
+                    const int s_uprv = prv != u ? a.tabu[udir_pos(u, prv, n)] : 0, s_prvv = a.tabu[udir_pos(prv, v, n)];
+                    const int s_vpru = pru != v ? a.tabu[udir_pos(v, pru, n)] : 0, s_pruu = a.tabu[udir_pos(pru, u, n)];
+                    const bool l_usu = live_v(s_usu), l_vs2 = live_v(s_vs2);
+                    int add = 0;
+                    bool edge = false;
                     if (!uv && !vu) {
-                        const int fu = live(u, su) ? 1 : 0, fv = live(v, s2) ? 1 : 0;
-                        tabu_cnt += 1 - fu - fv + fu * fv;
+                        const int fu = l_usu ? 1 : 0, fv = l_vs2 ? 1 : 0;
+                        add += 1 - fu - fv + fu * fv;
                     } else {
-                        tabu_cnt += n - 3;
-                        const int y = uv ? v : u, sy = uv ? s2 : su;
-                        if (live(y, sy)) tabu_cnt += 1;
+                        add += n - 3;
+                        if (uv ? l_vs2 : l_usu) add += 1;   // live(y, succ y), y = the edge's head
+                        edge = true;
+                    }
+                    // o = 0: aa = u, w = v, b = pred v;  o = 1: aa = v, w = u, b = pred u
+                    if (prv != u && u < prv && prv != su && !live_v(s_uprv) && !l_usu && !live_v(s_prvv)) add += 1;
+                    if (pru != v && v < pru && pru != s2 && !live_v(s_vpru) && !l_vs2 && !live_v(s_pruu)) add += 1;
+                    tabu_cnt += add;
+                    if (edge) {
                         // live tour edges of this sweep, cluster-wide (the C(|F|, 2) term): complete before this workgroup
                         // publishes its NEXT candidate; the first workgroup reads the count after that exchange
                         atomicAdd(a.tabu_side + 1 + slot_cur, 1ull);
                         __threadfence();
                     }
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        const int aa = o ? v : u, w = o ? u : v, sa = o ? s2 : su;
-                        const int b = npred(w);
-                        if (b != aa && aa < b && b != sa && !live(aa, b) && !live(aa, sa) && !live(b, w)) tabu_cnt += 1;
-                    }
                 }
+#ifdef TSP_STAMPS
+                if (tid == 64 && tour == 0 && c < 256) g_cl_tail[c][8] += wall_clock64() - ts0;
+#endif
             }
         }
         if (!probe_hit) {
@@ -1251,8 +1356,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 // (three slots in turn: the slot read and zeroed here is next added to two sweeps on, by workgroups that have
                 // seen this one's next candidate -- with two, a fast workgroup's adds of the next sweep could slip in before the read)
                 unsigned long long *fp = a.tabu_side + 1 + slot_prev;
+#ifdef TSP_STAMPS
+                const unsigned long long ta0 = wall_clock64();
+#endif
                 const long long f = (long long)atomicAdd(fp, 0ull);
                 if (f) { tabu_cnt -= f * (f - 1) / 2; atomicExch(fp, 0ull); __threadfence(); }   // zero again before this thread publishes the next candidate
+#ifdef TSP_STAMPS
+                if (tour == 0) g_cl_tail[0][9] += wall_clock64() - ta0;
+#endif
             }
         }
         CL_T(3);
@@ -1302,25 +1413,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 // b: (b, b1) becomes (a, b); b1: (b, b1) becomes (a1, b1) -- every other node keeps its two tour neighbours whatever
                 // the orientation.  So the bounds of their four groups are rebuilt from the OLD tour with those four edges patched,
                 // beside the reads of pa / pb and before the swaps: no barrier between the swaps and a rebuild.
-                const int a1 = (int)order[pa + 1 == n ? 0 : pa + 1], b1 = (int)order[pb + 1 == n ? 0 : pb + 1];
-                if (a.dbg & 1) {
-                    gmax_dirty = true;   // diagnostics: every bound rebuilt after the swaps (below)
-                } else if (wave >= 1 && wave <= 4) {   // (wave 0 computes the next sweep's bound meanwhile)
-                    const int g = wave == 1 ? (wi >> 6) : (wave == 2 ? (wj >> 6) : (wave == 3 ? (a1 >> 6) : (b1 >> 6)));
-                    const int v = g * 64 + lane;
-                    double m = 0.0;
-                    if (v < n) {
-                        const int p = (int)pos[v];
-                        int su = (int)order[p + 1 == n ? 0 : p + 1], pr = (int)order[p == 0 ? n - 1 : p - 1];
-                        if (v == wi) su = wj;            // a -> b
-                        else if (v == wj) su = wi;       // b's old successor b1 gives way to a
-                        if (v == a1) pr = b1;            // a1's old predecessor a gives way to b1
-                        else if (v == b1) pr = a1;       // b1's old predecessor b gives way to a1
-                        m = fmax(cl_dist<WT, INT, CT>(coord, v, su), cl_dist<WT, INT, CT>(coord, v, pr));
-                    }
-                    m = cl_wave_max_nonneg(m);
-                    if (lane == 0) gmax[g] = m;
-                }
+                if (a.dbg & 1) gmax_dirty = true;   // diagnostics: every bound rebuilt after the swaps (below)
+                else patch_bounds(wi, wj, pa, pb);
             }
             Lr = pb - pa; if (Lr < 0) Lr += n;
             const bool dbg_rebuild = SORTED && BEST && gmax_dirty;
@@ -1353,11 +1447,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             sweeps += 1;
             evals += (long long)n * (n - 1) / 2 - n;
             scanned += (long long)n * (n - 1) / 2;
-            if (found) { moves += 1; reversed += Lr - 1; }
+            bool have_run = false;   // a chain of iterations on integer costs: every workgroup keeps the cost as it goes (exact)
+            if constexpr (TABU && INT) have_run = a.chain_n > 0;
+            if (found) { moves += 1; reversed += Lr - 1; run_obj += bd; }
             else {
                 done = 1;
                 // recomputed cost in node order (tabusearch.c:168-172); only the first workgroup reports it
-                if (c == 0) {
+                if (have_run) obj = run_obj;
+                else if (c == 0) {
                     if constexpr (INT || WT == WT_CEIL_2D) {
                         double cc = 0.0;
                         for (int v = tid; v < n; v += kClThreads) cc += cl_node<WT, INT, CT>(coord, order, pos, n, v).ds;
@@ -1376,6 +1473,146 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             for (int t = 0; t < m; ++t) acc += s_chunk[t];
                         }
                         obj = acc;
+                    }
+                }
+            }
+            if constexpr (TABU) {
+                if (a.chain_n > 0 && done) {   // (the same in every workgroup: `done` follows from the exchange's result)
+                    // ---- the tail of iteration ck of tabu() (src/tabusearch.c:241-309), inside the launch ----------------------
+                    // What k_tabu_post_chain does between two launches of a queued chain: the incumbent (the first workgroup keeps
+                    // it), the first trial of the kick with the host-drawn nodes, and the next descent starts on the kicked replica
+                    // -- no write-back, no replica load, no kernel boundary.  The first workgroup decides the trial (reading the
+                    // stamps; its lazy clears are those of check_tenure, :83-92) and appends the two removed edges to the list;
+                    // its decision travels through one more exchange, and EVERY workgroup then carries the 2-exchange out on its
+                    // replica and stamps the two edges itself.
+                    // Memory between XCDs: the stamps are read and lazily cleared with plain loads and stores through the L2 of the
+                    // workgroup's XCD.  Inside one iteration a stale value is harmless (an expired stamp reads as expired or as 0:
+                    // iter and tenure are constant), across iterations it is not (the tenure changes).  So at this boundary every
+                    // workgroup writes its XCD's dirty lines back BEFORE it publishes (release), and drops what it holds AFTER the
+                    // exchange (acquire): whatever was cleared in this iteration is in memory before anybody reads a stamp for the
+                    // next one, and the stamps of the kick are written by each workgroup into its own L2 (the same value by all).
+                    const int ka = a.chain_par[5 * ck], kb = a.chain_par[5 * ck + 1];
+                    const int ia = a.chain_par[5 * ck + 3], ib = a.chain_par[5 * ck + 4];   // the same two nodes inside the replica
+                    int *res = a.chain + 4 + 10 * ck;
+                    int *s_kick = reinterpret_cast<int *>(s_chunk);   // {accepted, have0, have1, a1, b1}: the cost's chunks are through
+                    int better_inc = 0;
+                    __syncthreads();
+#ifdef TSP_STAMPS
+                    unsigned long long tt[7]; tt[0] = wall_clock64();
+#define CL_TT(k) do { if (tid == 0) tt[k] = wall_clock64(); } while (0)
+#else
+#define CL_TT(k) do { } while (0)
+#endif
+                    if (c == 0) {
+                        if (obj < inc_best) {
+                            better_inc = 1; inc_best = obj;
+                            for (int p = tid; p < n; p += kClThreads) a.snap[p] = a.gid[(int)order[p]];
+                        }
+                        if (tid == 0) {
+                            const int pa = (int)pos[ia], pb = (int)pos[ib];
+                            s_kick[3] = a.gid[(int)order[pa + 1 == n ? 0 : pa + 1]]; s_kick[4] = a.gid[(int)order[pb + 1 == n ? 0 : pb + 1]];
+                            s_kick[1] = 0; s_kick[2] = 0; s_kick[5] = 0;
+                        }
+                        __syncthreads();
+                        const int a1 = s_kick[3], b1 = s_kick[4];
+                        // the two edges a kick would stamp, looked up in the list of non-zero stamps by everybody (tabu_kick_body)
+                        // while the first thread decides the trial: both are one round trip to memory
+                        const int e0x = min(ka, a1), e0y = max(ka, a1), e1x = min(kb, b1), e1y = max(kb, b1);
+                        int2 *list = const_cast<int2 *>(a.tabu_list);
+                        if (tid == 0) {
+                            int acc = 0;
+                            if (!(ka == kb || a1 == kb || b1 == ka)) {
+                                // check_tenure on (a, a1), (b, b1), (a, b), (a1, b1) in the reference's order (:282-285): the four stamps are
+                                // read together, the && chain -- and with it the lazy clears -- runs on the values
+                                int *sp[4] = {a.tabu + udir_pos(ka, a1, n), a.tabu + udir_pos(kb, b1, n), a.tabu + udir_pos(ka, kb, n), a.tabu + udir_pos(a1, b1, n)};
+                                const int sv[4] = {*sp[0], *sp[1], *sp[2], *sp[3]};
+                                acc = 1;
+#pragma unroll
+                                for (int q = 0; q < 4 && acc; ++q) {
+                                    if (cur_iter < 0 || cur_ten < 0 || sv[q] == 0) continue;
+                                    if (cur_iter - sv[q] > cur_ten) *sp[q] = 0;
+                                    else acc = 0;
+                                }
+                            }
+                            s_kick[0] = acc;
+                        }
+                        if (cur_iter != 0) {   // a stamp of value 0 is no entry
+                            const int m = min(tl_m, a.tabu_list_cap);
+                            for (int k = tid; k < m; k += kClThreads) {
+                                const int2 e = list[k];
+                                if (e.x == e0x && e.y == e0y) s_kick[1] = 1;
+                                if (e.x == e1x && e.y == e1y) s_kick[2] = 1;
+                            }
+                        }
+                        __syncthreads();
+                        if (tid == 0 && s_kick[0] && cur_iter != 0) {
+                            int k = tl_m;   // past the capacity the count keeps running and the host stops using the list
+                            if (!s_kick[1]) { if (k < a.tabu_list_cap) list[k] = make_int2(e0x, e0y); ++k; }
+                            if (!s_kick[2] && !(e0x == e1x && e0y == e1y)) { if (k < a.tabu_list_cap) list[k] = make_int2(e1x, e1y); ++k; }
+                            *const_cast<int *>(a.tabu_list_n) = k;
+                            s_kick[5] = k - tl_m;
+                        }
+                        __syncthreads();
+                    }
+                    CL_TT(1);
+                    if (wave == 0) {
+                        // the decision travels as a candidate: the two successors a1, b1 (node ids) in the pair field, a and b inside the
+                        // replica in the internal-pair field, and -(1 + the entries the list has grown by) as the delta -- nobody has to look
+                        // anything up before the swaps or before the next sweep's pass over the list
+                        ClCand kc{0.0, kNoKey, 0u};
+                        if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)s_kick[5]; kc.key = make_key(s_kick[3], s_kick[4]); kc.ipair = ((unsigned)ia << 16) | (unsigned)ib; }
+                        __threadfence();   // release: this XCD's cleared stamps (and the first workgroup's list entries) are in memory
+                        CL_TT(2);
+                        bool okx = true;
+                        if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, kc, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
+                        CL_TT(3);
+                        __threadfence();   // acquire: nothing this CU or its L2 holds of the stamps / the list outlives the boundary
+                        CL_TT(4);
+                        if (lane == 0) { *s_win_d = kc.d; *s_win_k = kc.key; *s_win_ip = kc.ipair; *s_fail = okx ? 0 : 1; }
+                    }
+                    __syncthreads();
+                    if (*s_fail) { failed = true; break; }
+                    const bool kicked = *s_win_k != kNoKey;
+                    if (kicked) tl_m += (int)(-*s_win_d) - 1;
+                    const int ka1 = kicked ? key_i(*s_win_k) : 0, kb1 = kicked ? key_j(*s_win_k) : 0;
+                    if (kicked) {
+                        const int pa = (int)pos[ia], pb = (int)pos[ib];
+                        if (tid == 0) { a.tabu[udir_pos(ka, ka1, n)] = cur_iter; a.tabu[udir_pos(kb, kb1, n)] = cur_iter; }   // :306-309
+                        if constexpr (INT) {   // the running cost (exact: integer terms)
+                            const int a1i = (int)order[pa + 1 == n ? 0 : pa + 1], b1i = (int)order[pb + 1 == n ? 0 : pb + 1];
+                            run_obj += cl_dist<WT, INT, CT>(coord, ia, ib) + cl_dist<WT, INT, CT>(coord, a1i, b1i) -
+                                       cl_dist<WT, INT, CT>(coord, ia, a1i) - cl_dist<WT, INT, CT>(coord, ib, b1i);
+                        }
+                        patch_bounds(ia, ib, pa, pb);
+                        int Lk = pb - pa; if (Lk < 0) Lk += n;
+                        __syncthreads();   // everyone has read pa / pb
+                        ClView now{pa, pb, Lk};
+                        swaps(now, tid, kClThreads);
+                        __syncthreads();
+                    }
+#ifdef TSP_STAMPS
+                    if (tid == 0 && tour == 0 && c < 256) {
+                        tt[5] = wall_clock64();
+                        g_cl_tail[c][0] += tt[0] - tprev; g_cl_tail[c][1] += tt[1] - tt[0]; g_cl_tail[c][2] += tt[2] - tt[1]; g_cl_tail[c][3] += tt[3] - tt[2];
+                        g_cl_tail[c][4] += tt[4] - tt[3]; g_cl_tail[c][5] += tt[5] - tt[4]; g_cl_tail[c][7] += 1;
+                        tprev = tt[5];
+                    }
+#endif
+                    if (c == 0 && tid == 0) {   // res as k_tabu_post_chain leaves it; read by the host after the launch
+                        res[0] = kicked ? 1 : 0; res[1] = kicked ? ka1 : s_kick[3]; res[2] = kicked ? kb1 : s_kick[4]; res[3] = 0;
+                        res[4] = 1; res[5] = better_inc; res[6] = 0; res[7] = 0;
+                        *reinterpret_cast<double *>(res + 8) = obj;
+                        *reinterpret_cast<double *>(a.chain + 2) = inc_best;
+                        a.chain[1] = ck + 1;
+                        if (!kicked) a.chain[0] = 1;   // rejected: the host draws the next trial (tabusearch.c:262-287)
+                    }
+                    ck += 1;
+                    if (kicked && ck < a.chain_n) {   // the next iteration's alg_2opt_tabu, on the kicked tour
+                        done = 0;
+                        cur_iter = a.iter + ck; cur_ten = a.chain_par[5 * ck + 2];
+                        b0 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { b0_mem_d[q] = 0.0; b0_mem_ip[q] = 0u; }
                     }
                 }
             }
@@ -1588,6 +1825,12 @@ extern "C" int tsp_dev_debug_cluster(unsigned long long *out /* 256 x 8 */) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_prof), sizeof(unsigned long long) * 256 * 8) != hipSuccess) return -1;
     static unsigned long long z[256 * 8];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_prof), z, sizeof z);
+    return 0;
+}
+extern "C" int tsp_dev_debug_cluster_tail(unsigned long long *out /* 256 x 12 */) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tsp::g_cl_tail), sizeof(unsigned long long) * 256 * 12) != hipSuccess) return -1;
+    static unsigned long long z[256 * 12];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(tsp::g_cl_tail), z, sizeof z);
     return 0;
 }
 extern "C" int tsp_dev_debug_cluster_wstat(unsigned long long *out /* 256 x 4 */) {
@@ -1816,6 +2059,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu = tabu->d_stamp; a.tabu_list = tabu->d_list; a.tabu_list_n = tabu->d_list_n; a.tabu_list_cap = tabu->list_cap;
         a.tabu_side = tabu->d_tabu_pairs;
     }
+    a.chain = nullptr; a.chain_par = nullptr; a.chain_n = 0; a.snap = nullptr;
+    if (tabu && t->cl_ik_n > 0) {   // iterations of tabu() inside the launch (tsp_grid_tabu_iterations has filled the words)
+        if (!t->d_chain || !t->d_order_snap || max_steps >= 0) return TSP_DEV_E_ARG;
+        a.chain = t->d_chain; a.chain_par = t->d_chain + t->cl_ik_par; a.chain_n = t->cl_ik_n; a.snap = t->d_order_snap;
+    }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
     a.use_b0 = TSP_SW(inst, CLUSTER_B0, 1);
     a.defer_moves = TSP_SW(inst, CLUSTER_DEFER, 1);
@@ -1864,12 +2112,13 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         queued += a.max_iters;
         // exchange epochs run on from launch to launch (a tag of an earlier launch never equals a later epoch), so the area is
         // zeroed only when it is new, after a failed launch, and before the 32-bit epoch would wrap
-        if ((unsigned long long)t->cl_epoch + (unsigned)a.max_iters + 6ull >= 0xffffffffull) {
+        const unsigned epochs = (unsigned)a.max_iters + (unsigned)a.chain_n;   // (a chain of iterations: one more exchange per kick)
+        if ((unsigned long long)t->cl_epoch + epochs + 6ull >= 0xffffffffull) {
             TSP_HIP_TRY(hipMemsetAsync(t->d_cl_slots, 0, sizeof(unsigned long long) * t->cl_slot_words, s));
             t->cl_epoch = 0;
         }
         a.epoch0 = t->cl_epoch;
-        t->cl_epoch += ((unsigned)a.max_iters + 5u) & ~1u;   // even: the parity of an epoch picks the half of the area (+1: the arrival rendezvous)
+        t->cl_epoch += (epochs + 5u) & ~1u;   // even: the parity of an epoch picks the half of the area (+1: the arrival rendezvous)
         hipError_t e = hipSuccess;
         TSP_DISPATCH_METRIC(inst->wtype, inst->integer_cost, { e = cl_launch<WTC, INTC>(t, mode, on_fs ? pf : p, a); });
         if (e == hipSuccess && launches_done == 0 && t->cl_post) {   // a driver's follow-up, decided on the device (see tsp_dev_tours::cl_post)

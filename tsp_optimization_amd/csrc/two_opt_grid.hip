@@ -808,7 +808,8 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     rc = kick_buffers(t);
     if (rc) return rc;
     hipStream_t s = t->inst->ctx->stream;
-    const size_t chain_ints = 4 + 10 * (size_t)kMaxChain;
+    const size_t chain_ints = 4 + 10 * (size_t)kMaxChain + 5 * (size_t)kMaxChain;   // + {a, b, tenure, a and b in rank order} per iteration (in-kernel chains)
+    const int par_at = 4 + 10 * kMaxChain;
     if (!t->d_chain) {
         TSP_HIP_TRY(hipMalloc(&t->d_chain, chain_ints * sizeof(int)));
         TSP_HIP_TRY(hipHostMalloc(&t->h_chain, chain_ints * sizeof(int)));
@@ -816,10 +817,81 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     if (!t->d_order_snap) TSP_HIP_TRY(hipMalloc(&t->d_order_snap, (size_t)t->n * sizeof(int)));
     memset(t->h_chain, 0, chain_ints * sizeof(int));
     memcpy(t->h_chain + 2, best_obj, sizeof(double));
+    const bool in_kernel = TSP_SW(t->inst, TABU_INKERNEL, 1) != 0;
+    if (in_kernel)
+        for (int k = 0; k < count; ++k) {
+            int *q = t->h_chain + par_at + 5 * k;
+            q[0] = ab[2 * k]; q[1] = ab[2 * k + 1]; q[2] = tenure[k];
+            q[3] = t->inst->h_sinv[(size_t)ab[2 * k]]; q[4] = t->inst->h_sinv[(size_t)ab[2 * k + 1]];   // the two nodes inside the rank-order replica
+        }
     TSP_HIP_TRY(hipMemcpyAsync(t->d_chain, t->h_chain, chain_ints * sizeof(int), hipMemcpyHostToDevice, s));
     rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
     if (rc) return rc;
     TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+    if (in_kernel) {
+        // The iterations run INSIDE the CLUSTER launch (k_cluster_two_opt, TABU variant, chain_n > 0): between two descents the
+        // kernel itself keeps the incumbent, decides the kick's first trial and carries it out on the replicas -- what
+        // k_tabu_post_chain does between two launches of a queued chain, without the write-back, the replica load and the two
+        // kernel boundaries (28 + 4.6 + ~8 us of an iteration of ~140 at n = 10 000).  A launch that runs out of sweeps in the
+        // middle of an iteration writes its state back and the next launch goes on at chain[1].
+        t->cl_ik_n = count; t->cl_ik_par = par_at;
+        int done = 0, fell = 0;
+        const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, &done, &fell, tabu, iter0, tenure[0]);
+        t->cl_ik_n = 0;
+        t->h_state_fresh = false;
+        if (status < 0 && !fell) return status;
+        if (!fell) {
+            hipLaunchKernelGGL(k_tabu_fix_evals, dim3(1), dim3(64), 0, s, t->d_state, tabu->d_tabu_pairs);
+            TSP_HIP_TRY(hipGetLastError());
+        }
+        TSP_HIP_TRY(hipMemcpyAsync(t->h_chain, t->d_chain, chain_ints * sizeof(int), hipMemcpyDeviceToHost, s));
+        TSP_HIP_TRY(hipStreamSynchronize(s));
+        (void)hipGetLastError();
+        int nc = 0;
+        for (int k = 0; k < count; ++k) {
+            const int *res = t->h_chain + 4 + 10 * k;
+            if (!res[4]) break;
+            double c;
+            memcpy(&c, res + 8, sizeof c);
+            if (obj) obj[k] = c;
+            if (improved) improved[k] = res[5];
+            if (res[5]) t->h_obj_snap.assign(1, c);
+            if (res[0] && tabu->list_valid) {
+                tabu->list_ub += 2;
+                if (tabu->list_ub > tabu->list_cap) tabu->list_valid = false;
+            }
+            if (last_accepted) *last_accepted = res[0];
+            ++nc;
+        }
+        if (fell) {
+            // The exchange gave up.  In the launch's first exchanges nothing of the search state has been touched (the list may have
+            // two entries more than stamps: a superset is what it has to be): the host takes the other path.  Later -- a workgroup
+            // that had been resident stopped answering in the middle of a chain -- the kicks of the completed iterations are in
+            // the stamps while the tour in HBM is the one the launch started from: that is not recoverable here.
+            if (nc == 0) { if (tabu->list_valid) tabu->list_ub += 2; return TSP_OK; }
+            tsp::set_last_error("k_cluster_two_opt: the exchange gave up in the middle of a chain of tabu() iterations", hipErrorLaunchFailure, __FILE__, __LINE__);
+            return TSP_DEV_E_HIP;
+        }
+        tabu->last_run_list = true;
+        memcpy(best_obj, t->h_chain + 2, sizeof(double));
+        *completed = nc;
+        if (status == TSP_TIME_LIMIT_EXCEEDED && nc < count) {
+            // iteration nc was cut short: its tour and recomputed cost are in HBM, and the incumbent is updated before the status is
+            // looked at (tabusearch.c:241-249, :255) -- reported in slot nc, which is not counted as completed
+            TSP_HIP_TRY(hipMemcpyAsync(t->h_state, t->d_state, sizeof(TourState), hipMemcpyDeviceToHost, s));
+            TSP_HIP_TRY(hipStreamSynchronize(s));
+            const double c = t->h_state[0].obj;
+            if (obj) obj[nc] = c;
+            if (improved) improved[nc] = 0;
+            if (c < *best_obj) {
+                *best_obj = c;
+                if (improved) improved[nc] = 1;
+                const int rc2 = tsp_grid_snapshot(t, false);
+                if (rc2) return rc2;
+            }
+        }
+        return status == TSP_TIME_LIMIT_EXCEEDED ? status : TSP_OK;
+    }
     struct Chain { tsp_dev_tours *t; tsp_dev_tabu *tabu; int iter0, count; const int *tenure, *ab; } ch{t, tabu, iter0, count, tenure, ab};
     auto post = [](void *ctx, hipStream_t st, int k, const int *d_err) {   // ONE launch between two CLUSTER launches: evaluation count, incumbent, kick, re-arm
         Chain *q = static_cast<Chain *>(ctx);

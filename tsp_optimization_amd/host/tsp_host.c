@@ -577,6 +577,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
      * chain is made one and a half times as long as the chains have lately run (rand10000, step policy: one first trial in
      * twelve is rejected, chains run ten iterations on average; one in six at n = 299) */
     double mean_run = 8.0;
+    const int trace = getenv("TSP_HOST_TRACE") != NULL;
     struct timeval tl0, tl1;
     gettimeofday(&tl0, 0);
     long long st_chains = 0, st_queued = 0, st_done = 0, st_single = 0, st_retrials = 0;   /* TSP_HOST_STATS=1: printed at the end */
@@ -593,7 +594,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         if (policy == 2)
             for (int k = 0; k < K - 1; k++)
                 if (iter + k == 1 || (iter + k) % 100 == 0) { K = k + 1; break; }
-        int tenures[64], ab[128], improved[64];
+        int tenures[64], ab[128], improved[64] = {0};
         long raw[128];
         double objs[64];
         {
@@ -611,7 +612,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         pthread_mutex_unlock(&g_lock);
         if (rc < 0) dev_fail("tsp_dev_tours_tabu_iterations", rc);
         st_chains++; st_queued += K; st_done += completed;
-        for (int k = 0; k < completed; k++) if (improved[k]) have_best = 1;   /* the incumbent is updated before the status is looked at (:241-249, :255) */
+        for (int k = 0; k < completed; k++) if (improved[k]) have_best = 1;
+        if (rc > 0 && completed < K && improved[completed]) have_best = 1;   /* cut short by the time limit: the incumbent is updated before the status is looked at (:241-249, :255) */
         if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); host_random_unget(raw + 2 * completed, 2 * (K - completed)); break; }
         if (completed == 0) {
             /* the chain did not apply, or its first iteration could not be finished on the device: this iteration the one-wait
@@ -628,6 +630,12 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
             completed = 1; st_single++;
         } else {
             host_random_unget(raw + 2 * completed, 2 * (K - completed));
+        }
+        if (trace) {   /* TSP_HOST_TRACE=1: one line per iteration (a divergence between two runs shows at its first iteration) */
+            if (iter == 1) fprintf(stderr, "[tabu-trace] start obj %.0f\n", obj0);
+            for (int k = 0; k < completed; k++)
+                fprintf(stderr, "[tabu-trace] iter %d tenure %d a %d b %d obj %.0f%s\n", iter + k, tenures[k], ab[2 * k], ab[2 * k + 1],
+                        st_single && completed == 1 && k == 0 ? -1.0 : objs[k], k == completed - 1 ? (accepted ? " +" : " -") : " +");
         }
         mean_run = 0.75 * mean_run + 0.25 * completed;
         /* every completed iteration but the last had its kick accepted (the chain stops at a rejection) */
