@@ -219,8 +219,8 @@ int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter,
                                  double *best_obj, double *obj, int *improved, int *accepted);
 /* `count` (<= 64) iterations of tabu() in ONE wait for the device: iteration iter0 + k runs alg_2opt_tabu with tenure[k], updates
  * the incumbent and makes the FIRST trial of its kick with the host-drawn nodes ab[2k], ab[2k + 1] (what
- * tsp_dev_tours_tabu_iteration does for one iteration) -- the launches are queued back to back and a word on the device stops the
- * chain as soon as an iteration cannot be completed there.  *completed = iterations that ran up to their kick's trial; obj[k] /
+ * tsp_dev_tours_tabu_iteration does for one iteration) -- the iterations run inside one launch of the CLUSTER engine (or, TSP_TABU_INKERNEL=0, as launches queued back
+ * to back) and a word on the device stops the chain as soon as an iteration cannot be completed there.  *completed = iterations that ran up to their kick's trial; obj[k] /
  * improved[k] are filled for those.  *last_accepted = 0: the trial of iteration iter0 + *completed - 1 was rejected (edges that
  * share a node, or tabu): the caller draws further trials for it (tsp_dev_tours_tabu_kick) and goes on; the pairs ab[2k ..] of
  * the iterations that did not run have not been consumed (the caller serves them first: the libc stream stays the
@@ -229,6 +229,18 @@ int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter,
  * apply here (another engine, a list too long for it); nothing was touched. */
 int tsp_dev_tours_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab,
                                   double time_limit_s, double *best_obj, double *obj, int *improved, int *completed, int *last_accepted);
+/* The same with the kick's FURTHER trials on the device too (src/tabusearch.c:262-287 draws pairs until one is accepted): ab holds
+ * `pairs` (count <= pairs <= 128) node pairs in the order tabu() would draw them, and the iterations take them in that order --
+ * iteration iter0 + k starts with the pair after the last one iteration iter0 + k - 1 took, and a rejected trial is followed by
+ * the next pair, all inside the launch (the CLUSTER engine's tabu variant runs the iterations itself: incumbent, trials, kick
+ * and the next descent on the replicas).  trials[k] = pairs iteration k took (>= 1); the caller has consumed
+ * sum(trials[0 .. *completed - 1]) pairs and serves the rest of its look-ahead first.  *last_accepted = 0 only when the pairs ran
+ * out in the middle of an iteration's trials: the caller draws on (tsp_dev_tours_tabu_kick).  Everything else as above.  Where
+ * the iterations cannot run inside a launch (TSP_TABU_INKERNEL=0, another engine) *completed = 0 and the caller takes
+ * tsp_dev_tours_tabu_iterations. */
+int tsp_dev_tours_tabu_iterations_ex(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, int pairs, const int *ab,
+                                     double time_limit_s, double *best_obj, double *obj, int *improved, int *trials, int *completed,
+                                     int *last_accepted);
 /* kick() of src/vns.c:11-100 with the three host-drawn, sorted tour positions p1 < p2 < p3 (positions of the walk from
  * node 0): segments tour[p1+1..p2] and tour[p2+1..p3] swap places; the recomputed cost (:77-86) goes to the control block
  * and to *obj (may be NULL). */

@@ -478,3 +478,56 @@ def test_chain_of_tabu_iterations_equals_the_iterations_one_by_one(eng, ctx, in_
     for x in (t1, t2, tb1, tb2):
         x.close()
     inst.close()
+
+
+def test_chain_with_the_kicks_further_trials_on_the_device_equals_the_replay_one_by_one(eng, ctx):
+    """tsp_dev_tours_tabu_iterations_ex: the kick's trials are taken in order from the host-drawn pairs, a rejected one followed by
+    the next INSIDE the launch (tabusearch.c:262-287).  Replay: tsp_dev_tours_tabu_iteration with the iteration's first pair, then
+    tsp_dev_tours_tabu_kick with the following pairs until one is accepted.  Same costs, incumbent, trials per iteration, tour,
+    stamps and work counters; when the pairs run out in the middle of an iteration's trials the chain stops there."""
+    xy, wt = load_instance("pr1002")
+    n = len(xy)
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    rng = np.random.default_rng(11)
+    K, P = 9, 14
+    tenures = [25 + (k % 4) for k in range(K)]
+    ab = rng.integers(0, n, size=(P, 2)).astype(np.int32)
+    ab[2] = (77, 77)                      # rejected: a == b (:271-273)
+    ab[3] = (500, 500)                    # ... and the trial after it too
+    ab[8] = (9, 9)
+
+    def handle():
+        t, tb = eng.Tours(inst, 1), eng.Tabu(inst)
+        t.upload(succ0, obj0)
+        return t, tb
+    t1, tb1 = handle()
+    t2, tb2 = handle()
+    best, objs, trials, p = float("inf"), [], [], 0
+    for k in range(K):
+        rc, obj, best, improved, acc = t1.tabu_iteration(tb1, 1 + k, tenures[k], int(ab[p, 0]), int(ab[p, 1]), best)
+        assert rc == 0
+        used = 1; p += 1
+        while not acc:
+            acc = t1.tabu_kick(tb1, int(ab[p, 0]), int(ab[p, 1]), 1 + k, tenures[k])
+            used += 1; p += 1
+        objs.append(obj); trials.append(used)
+    assert p <= P and max(trials) == 3
+    rc, done, last_acc, best2, obj2, imp2, tri2 = t2.tabu_iterations_ex(tb2, 1, tenures, ab, float("inf"))
+    assert rc == 0 and done == K and last_acc
+    assert list(obj2) == objs and best2 == best and list(tri2) == trials
+    sa, oa, sta = t1.download()
+    sb, ob, stb = t2.download()
+    assert (sa[0] == sb[0]).all() and oa[0] == ob[0] and (tb1.download() == tb2.download()).all()
+    for key in ("sweeps", "evals", "moves", "reversed"):
+        assert sta[0][key] == stb[0][key], key
+    t1.restore(); t2.restore()
+    assert (t1.download()[0][0] == t2.download()[0][0]).all()
+    # the pairs run out inside an iteration's trials: the chain ends there, that iteration's kick is the caller's to finish
+    ab2 = rng.integers(0, n, size=(3, 2)).astype(np.int32)
+    ab2[1] = (4, 4); ab2[2] = (5, 5)
+    rc, done, last_acc, best3, obj3, imp3, tri3 = t2.tabu_iterations_ex(tb2, 1 + K, [30, 30, 30], ab2, best2)
+    assert rc == 0 and done == 2 and not last_acc and list(tri3) == [1, 2]
+    for x in (t1, t2, tb1, tb2):
+        x.close()
+    inst.close()

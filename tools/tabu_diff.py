@@ -1,0 +1,35 @@
+"""First iteration at which two ways of running tabu() differ (TSP_HOST_TRACE lines): in-kernel chains against queued chains.
+usage (gpurun): tabu_diff.py [instance] [policy] [iterations]"""
+import ctypes as C, os, sys, subprocess
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "--child":
+    sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
+    from helpers import HostInstance, Instance
+    from tsp_optimization_amd.build import lib_path
+    name, policy, iters = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    L = C.CDLL(lib_path("libtsp_host.so"))
+    L.tsp_host_tabu.argtypes = [C.POINTER(Instance), C.c_int, C.c_longlong]
+    h = HostInstance(name); h.c.params.time_limit = 600
+    C.CDLL(None).srandom(123)
+    L.tsp_host_tabu(C.byref(h.c), policy, iters)
+    print("final", h.obj)
+    sys.exit(0)
+name = sys.argv[1] if len(sys.argv) > 1 else "pr299"
+policy = sys.argv[2] if len(sys.argv) > 2 else "1"
+iters = sys.argv[3] if len(sys.argv) > 3 else "120"
+out = {}
+for mode in ("1", "0"):
+    env = dict(os.environ, TSP_TABU_INKERNEL=mode, TSP_HOST_TRACE="1")
+    p = subprocess.run([sys.executable, __file__, "--child", name, policy, iters], env=env, capture_output=True, text=True)
+    lines = [l.split(" trials")[0] + " obj" + l.split(" obj")[1] for l in p.stderr.splitlines() if l.startswith("[tabu-trace] iter")]
+    out[mode] = (lines, p.stdout.strip(), [l for l in p.stderr.splitlines() if l.startswith("[tabu-trace] iter")])
+    print("inkernel=%s: %d trace lines, %s" % (mode, len(lines), p.stdout.strip()))
+a, b = out["1"][0], out["0"][0]
+for k, (x, y) in enumerate(zip(a, b)):
+    if x != y:
+        print("first difference at line", k)
+        print(" in-kernel:", out["1"][2][max(0, k - 3):k + 2])
+        print(" queued   :", out["0"][2][max(0, k - 3):k + 2])
+        break
+else:
+    print("identical" if len(a) == len(b) else "one is a prefix of the other")

@@ -173,8 +173,8 @@ int tsp_grid_snapshot(tsp_dev_tours *t, bool restore);
 int tsp_grid_resident_tabu(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, double *obj);
 int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
                             double *best_obj, double *obj, int *improved, int *accepted);
-int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab, double time_limit_s,
-                             double *best_obj, double *obj, int *improved, int *completed, int *last_accepted);
+int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, int pairs, const int *ab, double time_limit_s,
+                             double *best_obj, double *obj, int *improved, int *trials, int *completed, int *last_accepted);
 
 extern "C" {
 
@@ -606,7 +606,15 @@ int tsp_dev_tours_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter
                                   double time_limit_s, double *best_obj, double *obj, int *improved, int *completed, int *last_accepted) {
     if (!t) return TSP_DEV_E_ARG;
     TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
-    return tsp_grid_tabu_iterations(t, tabu, iter0, count, tenure, ab, time_limit_s, best_obj, obj, improved, completed, last_accepted);
+    return tsp_grid_tabu_iterations(t, tabu, iter0, count, tenure, 0, ab, time_limit_s, best_obj, obj, improved, nullptr, completed, last_accepted);
+}
+
+int tsp_dev_tours_tabu_iterations_ex(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, int pairs, const int *ab,
+                                     double time_limit_s, double *best_obj, double *obj, int *improved, int *trials, int *completed,
+                                     int *last_accepted) {
+    if (!t || pairs < count) return TSP_DEV_E_ARG;
+    TSP_HIP_TRY(hipSetDevice(t->inst->ctx->device));
+    return tsp_grid_tabu_iterations(t, tabu, iter0, count, tenure, pairs, ab, time_limit_s, best_obj, obj, improved, trials, completed, last_accepted);
 }
 
 int tsp_dev_tours_vns_kick(tsp_dev_tours *t, int p1, int p2, int p3, double *obj) {

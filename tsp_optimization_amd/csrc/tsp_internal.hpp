@@ -206,9 +206,10 @@ struct tsp_dev_tours {
     int *d_chain = nullptr;
     int *h_chain = nullptr;          // pinned mirror
     // ... or INSIDE one launch (TSP_TABU_INKERNEL, the default): the kernel runs cl_ik_n iterations with the kick's first trials
-    // d_chain + cl_ik_par = {a, b, tenure} per iteration, keeps the incumbent in d_order_snap and writes the same result words
+    // the tenures and the host-drawn kick trials behind the result words of d_chain, keeps the incumbent in d_order_snap and writes the same result words
     int cl_ik_n = 0;
-    int cl_ik_par = 0;
+    int cl_ik_par = 0;               // offsets into d_chain: the tenures, ...
+    int cl_ik_pairs = 0, cl_ik_ab = 0, cl_ik_pp = 0;   // ... the kick trials (count; 0 = one per iteration), and where the next trial's index lives
     bool h_state_fresh = false;   // h_state holds what d_state holds (set by a CLUSTER run's last poll, cleared by whatever queues work after it)
     int *h_cl_err = nullptr;         // pinned: the CLUSTER engine's error word, read with every poll
     bool tabu_list_run = false;      // the current tsp_grid_run goes through k_sweep<TABU> (two_opt_tabu_list.hpp)

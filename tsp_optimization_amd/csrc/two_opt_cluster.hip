@@ -91,11 +91,14 @@ struct ClusterArgs {
     int tabu_list_cap, iter, tenure;
     unsigned long long *tabu_side;
     // iterations of tabu() inside the launch (TABU variant; chain_n == 0: one descent, as ever): chain = {stop word, next iteration
-    // of the chain, the incumbent's cost (double), 10 result words per iteration}, chain_par = {a, b, tenure, a and b inside the replica} per
-    // iteration (the kick's first trial, host-drawn), snap = the incumbent's tour (nodes by position)
+    // of the chain, the incumbent's cost (double), 10 result words per iteration}, chain_par = the tenure per iteration; the kick's trials are host-drawn (chain_ab), snap = the incumbent's tour (nodes by position)
     int *chain;
     const int *chain_par;
     int chain_n;
+    int chain_pairs;        // > 0: the kick's trials are taken IN ORDER from chain_ab (a rejected trial is followed by the next pair, as tabu()
+                            // draws them: tabusearch.c:262-287), chain_pp = where the next one is; 0: trial k belongs to iteration k, one each
+    const int *chain_ab;    // {a, b, a and b inside the replica} per pair
+    int *chain_pp;
     int *snap;
     int probe;              // FIRST: largest distance (pairs) of the last hit after which a step starts with the probe; 0 = never
     int defer_moves;        // carry the swaps of a move out during the next step's exchange (TSP_CLUSTER_DEFER)
@@ -508,13 +511,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     gu64 *area = (gu64 *)a.slots + (size_t)tour * 2 * kClCopies * C * kClSlotGranules;
     // the iteration of tabu() this launch is at (its number and tenure decide what is tabu): a launch that carries a chain of
     // iterations goes on where the launch before it stopped (chain[1])
-    int cur_iter = a.iter, cur_ten = a.tenure, ck = 0;
+    int cur_iter = a.iter, cur_ten = a.tenure, ck = 0, kpp = 0;   // kpp: the pair the next kick trial takes
     double inc_best = 0.0;
     if constexpr (TABU) {
         if (a.chain_n > 0) {
             ck = a.chain[1];
-            cur_iter = a.iter + ck; cur_ten = a.chain_par[5 * ck + 2];
+            cur_iter = a.iter + ck; cur_ten = a.chain_par[ck];
             inc_best = *reinterpret_cast<const double *>(a.chain + 2);
+            kpp = a.chain_pairs > 0 ? *a.chain_pp : ck;
         }
     }
 
@@ -1491,11 +1495,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     // workgroup writes its XCD's dirty lines back BEFORE it publishes (release), and drops what it holds AFTER the
                     // exchange (acquire): whatever was cleared in this iteration is in memory before anybody reads a stamp for the
                     // next one, and the stamps of the kick are written by each workgroup into its own L2 (the same value by all).
-                    const int ka = a.chain_par[5 * ck], kb = a.chain_par[5 * ck + 1];
-                    const int ia = a.chain_par[5 * ck + 3], ib = a.chain_par[5 * ck + 4];   // the same two nodes inside the replica
+                    const int npairs = a.chain_pairs > 0 ? a.chain_pairs : a.chain_n;
                     int *res = a.chain + 4 + 10 * ck;
-                    int *s_kick = reinterpret_cast<int *>(s_chunk);   // {accepted, have0, have1, a1, b1}: the cost's chunks are through
-                    int better_inc = 0;
+                    int *s_kick = reinterpret_cast<int *>(s_chunk);   // {accepted, have0, have1, a1, b1, entries appended, pair taken}: the cost's chunks are through
+                    int better_inc = 0, trials = 0;
                     __syncthreads();
 #ifdef TSP_STAMPS
                     unsigned long long tt[7]; tt[0] = wall_clock64();
@@ -1508,59 +1511,67 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             better_inc = 1; inc_best = obj;
                             for (int p = tid; p < n; p += kClThreads) a.snap[p] = a.gid[(int)order[p]];
                         }
-                        if (tid == 0) {
-                            const int pa = (int)pos[ia], pb = (int)pos[ib];
-                            s_kick[3] = a.gid[(int)order[pa + 1 == n ? 0 : pa + 1]]; s_kick[4] = a.gid[(int)order[pb + 1 == n ? 0 : pb + 1]];
-                            s_kick[1] = 0; s_kick[2] = 0; s_kick[5] = 0;
-                        }
-                        __syncthreads();
-                        const int a1 = s_kick[3], b1 = s_kick[4];
-                        // the two edges a kick would stamp, looked up in the list of non-zero stamps by everybody (tabu_kick_body)
-                        // while the first thread decides the trial: both are one round trip to memory
-                        const int e0x = min(ka, a1), e0y = max(ka, a1), e1x = min(kb, b1), e1y = max(kb, b1);
                         int2 *list = const_cast<int2 *>(a.tabu_list);
-                        if (tid == 0) {
-                            int acc = 0;
-                            if (!(ka == kb || a1 == kb || b1 == ka)) {
-                                // check_tenure on (a, a1), (b, b1), (a, b), (a1, b1) in the reference's order (:282-285): the four stamps are
-                                // read together, the && chain -- and with it the lazy clears -- runs on the values
-                                int *sp[4] = {a.tabu + udir_pos(ka, a1, n), a.tabu + udir_pos(kb, b1, n), a.tabu + udir_pos(ka, kb, n), a.tabu + udir_pos(a1, b1, n)};
-                                const int sv[4] = {*sp[0], *sp[1], *sp[2], *sp[3]};
-                                acc = 1;
+                        for (int pp = kpp;; ++pp) {   // the trials of this iteration's kick, in the order tabu() draws them
+                            const int ka = a.chain_ab[4 * pp], kb = a.chain_ab[4 * pp + 1];
+                            const int ia = a.chain_ab[4 * pp + 2], ib = a.chain_ab[4 * pp + 3];   // the same two nodes inside the replica
+                            if (tid == 0) {
+                                const int pa = (int)pos[ia], pb = (int)pos[ib];
+                                s_kick[3] = a.gid[(int)order[pa + 1 == n ? 0 : pa + 1]]; s_kick[4] = a.gid[(int)order[pb + 1 == n ? 0 : pb + 1]];
+                                s_kick[1] = 0; s_kick[2] = 0; s_kick[5] = 0; s_kick[6] = pp;
+                            }
+                            __syncthreads();
+                            const int a1 = s_kick[3], b1 = s_kick[4];
+                            // the two edges a kick would stamp, looked up in the list of non-zero stamps by everybody (tabu_kick_body)
+                            // while the first thread decides the trial: both are one round trip to memory
+                            const int e0x = min(ka, a1), e0y = max(ka, a1), e1x = min(kb, b1), e1y = max(kb, b1);
+                            if (tid == 0) {
+                                int acc = 0;
+                                if (!(ka == kb || a1 == kb || b1 == ka)) {
+                                    // check_tenure on (a, a1), (b, b1), (a, b), (a1, b1) in the reference's order (:282-285): the four stamps
+                                    // are read together, the && chain -- and with it the lazy clears -- runs on the values
+                                    int *sp[4] = {a.tabu + udir_pos(ka, a1, n), a.tabu + udir_pos(kb, b1, n), a.tabu + udir_pos(ka, kb, n), a.tabu + udir_pos(a1, b1, n)};
+                                    const int sv[4] = {*sp[0], *sp[1], *sp[2], *sp[3]};
+                                    acc = 1;
 #pragma unroll
-                                for (int q = 0; q < 4 && acc; ++q) {
-                                    if (cur_iter < 0 || cur_ten < 0 || sv[q] == 0) continue;
-                                    if (cur_iter - sv[q] > cur_ten) *sp[q] = 0;
-                                    else acc = 0;
+                                    for (int q = 0; q < 4 && acc; ++q) {
+                                        if (cur_iter < 0 || cur_ten < 0 || sv[q] == 0) continue;
+                                        if (cur_iter - sv[q] > cur_ten) *sp[q] = 0;
+                                        else acc = 0;
+                                    }
+                                }
+                                s_kick[0] = acc;
+                            }
+                            if (cur_iter != 0) {   // a stamp of value 0 is no entry
+                                const int m = min(tl_m, a.tabu_list_cap);
+                                for (int k = tid; k < m; k += kClThreads) {
+                                    const int2 e = list[k];
+                                    if (e.x == e0x && e.y == e0y) s_kick[1] = 1;
+                                    if (e.x == e1x && e.y == e1y) s_kick[2] = 1;
                                 }
                             }
-                            s_kick[0] = acc;
-                        }
-                        if (cur_iter != 0) {   // a stamp of value 0 is no entry
-                            const int m = min(tl_m, a.tabu_list_cap);
-                            for (int k = tid; k < m; k += kClThreads) {
-                                const int2 e = list[k];
-                                if (e.x == e0x && e.y == e0y) s_kick[1] = 1;
-                                if (e.x == e1x && e.y == e1y) s_kick[2] = 1;
+                            __syncthreads();
+                            if (tid == 0 && s_kick[0] && cur_iter != 0) {
+                                int k = tl_m;   // past the capacity the count keeps running and the host stops using the list
+                                if (!s_kick[1]) { if (k < a.tabu_list_cap) list[k] = make_int2(e0x, e0y); ++k; }
+                                if (!s_kick[2] && !(e0x == e1x && e0y == e1y)) { if (k < a.tabu_list_cap) list[k] = make_int2(e1x, e1y); ++k; }
+                                *const_cast<int *>(a.tabu_list_n) = k;
+                                s_kick[5] = k - tl_m;
                             }
+                            ++trials;
+                            const bool again = !s_kick[0] && a.chain_pairs > 0 && pp + 1 < npairs;   // (the same in every thread: read behind the barrier)
+                            __syncthreads();
+                            if (!again) break;
                         }
-                        __syncthreads();
-                        if (tid == 0 && s_kick[0] && cur_iter != 0) {
-                            int k = tl_m;   // past the capacity the count keeps running and the host stops using the list
-                            if (!s_kick[1]) { if (k < a.tabu_list_cap) list[k] = make_int2(e0x, e0y); ++k; }
-                            if (!s_kick[2] && !(e0x == e1x && e0y == e1y)) { if (k < a.tabu_list_cap) list[k] = make_int2(e1x, e1y); ++k; }
-                            *const_cast<int *>(a.tabu_list_n) = k;
-                            s_kick[5] = k - tl_m;
-                        }
-                        __syncthreads();
                     }
                     CL_TT(1);
                     if (wave == 0) {
                         // the decision travels as a candidate: the two successors a1, b1 (node ids) in the pair field, a and b inside the
-                        // replica in the internal-pair field, and -(1 + the entries the list has grown by) as the delta -- nobody has to look
+                        // replica in the internal-pair field, and -(1 + the entries the list has grown by + 4 x the pair that was taken) as the delta
+                        // -- nobody has to look
                         // anything up before the swaps or before the next sweep's pass over the list
                         ClCand kc{0.0, kNoKey, 0u};
-                        if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)s_kick[5]; kc.key = make_key(s_kick[3], s_kick[4]); kc.ipair = ((unsigned)ia << 16) | (unsigned)ib; }
+                        if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)(s_kick[5] + 4 * s_kick[6]); kc.key = make_key(s_kick[3], s_kick[4]); kc.ipair = ((unsigned)a.chain_ab[4 * s_kick[6] + 2] << 16) | (unsigned)a.chain_ab[4 * s_kick[6] + 3]; }
                         __threadfence();   // release: this XCD's cleared stamps (and the first workgroup's list entries) are in memory
                         CL_TT(2);
                         bool okx = true;
@@ -1573,11 +1584,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     __syncthreads();
                     if (*s_fail) { failed = true; break; }
                     const bool kicked = *s_win_k != kNoKey;
-                    if (kicked) tl_m += (int)(-*s_win_d) - 1;
+                    const int kword = kicked ? (int)(-*s_win_d) - 1 : 0, ptaken = kword >> 2;
+                    if (kicked) tl_m += kword & 3;
+                    const int ia = kicked ? (int)(*s_win_ip >> 16) : 0, ib = kicked ? (int)(*s_win_ip & 0xffffu) : 0;
                     const int ka1 = kicked ? key_i(*s_win_k) : 0, kb1 = kicked ? key_j(*s_win_k) : 0;
                     if (kicked) {
                         const int pa = (int)pos[ia], pb = (int)pos[ib];
-                        if (tid == 0) { a.tabu[udir_pos(ka, ka1, n)] = cur_iter; a.tabu[udir_pos(kb, kb1, n)] = cur_iter; }   // :306-309
+                        if (tid == 0) { a.tabu[udir_pos(a.chain_ab[4 * ptaken], ka1, n)] = cur_iter; a.tabu[udir_pos(a.chain_ab[4 * ptaken + 1], kb1, n)] = cur_iter; }   // :306-309
                         if constexpr (INT) {   // the running cost (exact: integer terms)
                             const int a1i = (int)order[pa + 1 == n ? 0 : pa + 1], b1i = (int)order[pb + 1 == n ? 0 : pb + 1];
                             run_obj += cl_dist<WT, INT, CT>(coord, ia, ib) + cl_dist<WT, INT, CT>(coord, a1i, b1i) -
@@ -1599,17 +1612,19 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     }
 #endif
                     if (c == 0 && tid == 0) {   // res as k_tabu_post_chain leaves it; read by the host after the launch
-                        res[0] = kicked ? 1 : 0; res[1] = kicked ? ka1 : s_kick[3]; res[2] = kicked ? kb1 : s_kick[4]; res[3] = 0;
+                        res[0] = kicked ? 1 : 0; res[1] = kicked ? ka1 : s_kick[3]; res[2] = kicked ? kb1 : s_kick[4]; res[3] = trials;
                         res[4] = 1; res[5] = better_inc; res[6] = 0; res[7] = 0;
                         *reinterpret_cast<double *>(res + 8) = obj;
                         *reinterpret_cast<double *>(a.chain + 2) = inc_best;
                         a.chain[1] = ck + 1;
-                        if (!kicked) a.chain[0] = 1;   // rejected: the host draws the next trial (tabusearch.c:262-287)
+                        if (a.chain_pairs > 0) *a.chain_pp = kpp + trials;
+                        if (!kicked) a.chain[0] = 1;   // rejected (and no pair left to try): the host draws the next trial (tabusearch.c:262-287)
                     }
                     ck += 1;
+                    kpp = a.chain_pairs > 0 ? ptaken + 1 : ck;
                     if (kicked && ck < a.chain_n) {   // the next iteration's alg_2opt_tabu, on the kicked tour
                         done = 0;
-                        cur_iter = a.iter + ck; cur_ten = a.chain_par[5 * ck + 2];
+                        cur_iter = a.iter + ck; cur_ten = a.chain_par[ck];
                         b0 = 0.0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { b0_mem_d[q] = 0.0; b0_mem_ip[q] = 0u; }
@@ -2059,10 +2074,11 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         a.tabu = tabu->d_stamp; a.tabu_list = tabu->d_list; a.tabu_list_n = tabu->d_list_n; a.tabu_list_cap = tabu->list_cap;
         a.tabu_side = tabu->d_tabu_pairs;
     }
-    a.chain = nullptr; a.chain_par = nullptr; a.chain_n = 0; a.snap = nullptr;
+    a.chain = nullptr; a.chain_par = nullptr; a.chain_n = 0; a.snap = nullptr; a.chain_pairs = 0; a.chain_ab = nullptr; a.chain_pp = nullptr;
     if (tabu && t->cl_ik_n > 0) {   // iterations of tabu() inside the launch (tsp_grid_tabu_iterations has filled the words)
         if (!t->d_chain || !t->d_order_snap || max_steps >= 0) return TSP_DEV_E_ARG;
         a.chain = t->d_chain; a.chain_par = t->d_chain + t->cl_ik_par; a.chain_n = t->cl_ik_n; a.snap = t->d_order_snap;
+        a.chain_pairs = t->cl_ik_pairs; a.chain_ab = t->d_chain + t->cl_ik_ab; a.chain_pp = t->d_chain + t->cl_ik_pp;
     }
     a.probe = TSP_SW(inst, CLUSTER_PROBE, 4096);
     a.use_b0 = TSP_SW(inst, CLUSTER_B0, 1);

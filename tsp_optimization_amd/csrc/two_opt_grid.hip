@@ -779,15 +779,22 @@ int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int 
 // trials, tsp_dev_tours_tabu_kick, before it goes on), and an iteration whose descent did not finish in its launch is not counted:
 // the host runs it through tsp_dev_tours_tabu_iteration.  Returns 0 with *completed = 0 when the chain does not apply (another
 // engine, a long list): nothing was touched.
-int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab, double time_limit_s,
-                             double *best_obj, double *obj, int *improved, int *completed, int *last_accepted) {
-    constexpr int kMaxChain = 64;
+int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, int pairs, const int *ab, double time_limit_s,
+                             double *best_obj, double *obj, int *improved, int *trials, int *completed, int *last_accepted) {
+    constexpr int kMaxChain = 64, kMaxPairs = 128;
     if (!t || !tabu || t->B != 1 || tabu->inst != t->inst || !best_obj || !tenure || !ab || !completed || count < 1) return TSP_DEV_E_ARG;
     *completed = 0;
     if (last_accepted) *last_accepted = 0;
     count = std::min(count, kMaxChain);
-    for (int k = 0; k < count; ++k)
-        if (ab[2 * k] < 0 || ab[2 * k] >= t->n || ab[2 * k + 1] < 0 || ab[2 * k + 1] >= t->n || tenure[k] < 0) return TSP_DEV_E_ARG;
+    // pairs > 0: the kick's trials in the order tabu() draws them -- a rejected one is followed by the next pair, inside the launch
+    // (the first `count` pairs are the iterations' first trials only as long as none is rejected); 0: ab[2k], ab[2k + 1] is the one
+    // trial of iteration k and the chain stops where it is rejected
+    if (pairs < 0 || (pairs > 0 && pairs < count)) return TSP_DEV_E_ARG;
+    pairs = std::min(pairs, kMaxPairs);
+    const int npairs = pairs > 0 ? pairs : count;
+    for (int k = 0; k < count; ++k) if (tenure[k] < 0) return TSP_DEV_E_ARG;
+    for (int k = 0; k < npairs; ++k)
+        if (ab[2 * k] < 0 || ab[2 * k] >= t->n || ab[2 * k + 1] < 0 || ab[2 * k + 1] >= t->n) return TSP_DEV_E_ARG;
     if (iter0 < 0) return TSP_DEV_E_ARG;
     // the chain rides on the CLUSTER engine's tabu variant: the conditions of tsp_tabu_run's first branch, and room in the list
     // of non-zero stamps for the two entries every accepted kick appends (no scan, no compaction inside a chain)
@@ -808,8 +815,9 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     rc = kick_buffers(t);
     if (rc) return rc;
     hipStream_t s = t->inst->ctx->stream;
-    const size_t chain_ints = 4 + 10 * (size_t)kMaxChain + 5 * (size_t)kMaxChain;   // + {a, b, tenure, a and b in rank order} per iteration (in-kernel chains)
-    const int par_at = 4 + 10 * kMaxChain;
+    // + in-kernel chains: the tenure per iteration, {a, b, a and b in rank order} per kick trial, the index of the next trial
+    const int par_at = 4 + 10 * kMaxChain, ab_at = par_at + kMaxChain, pp_at = ab_at + 4 * kMaxPairs;
+    const size_t chain_ints = (size_t)pp_at + 4;
     if (!t->d_chain) {
         TSP_HIP_TRY(hipMalloc(&t->d_chain, chain_ints * sizeof(int)));
         TSP_HIP_TRY(hipHostMalloc(&t->h_chain, chain_ints * sizeof(int)));
@@ -818,12 +826,14 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     memset(t->h_chain, 0, chain_ints * sizeof(int));
     memcpy(t->h_chain + 2, best_obj, sizeof(double));
     const bool in_kernel = TSP_SW(t->inst, TABU_INKERNEL, 1) != 0;
-    if (in_kernel)
-        for (int k = 0; k < count; ++k) {
-            int *q = t->h_chain + par_at + 5 * k;
-            q[0] = ab[2 * k]; q[1] = ab[2 * k + 1]; q[2] = tenure[k];
-            q[3] = t->inst->h_sinv[(size_t)ab[2 * k]]; q[4] = t->inst->h_sinv[(size_t)ab[2 * k + 1]];   // the two nodes inside the rank-order replica
+    if (in_kernel) {
+        for (int k = 0; k < count; ++k) t->h_chain[par_at + k] = tenure[k];
+        for (int k = 0; k < npairs; ++k) {
+            int *q = t->h_chain + ab_at + 4 * k;
+            q[0] = ab[2 * k]; q[1] = ab[2 * k + 1];
+            q[2] = t->inst->h_sinv[(size_t)ab[2 * k]]; q[3] = t->inst->h_sinv[(size_t)ab[2 * k + 1]];   // the two nodes inside the rank-order replica
         }
+    } else if (pairs > 0) return TSP_OK;   // (queued chains take one trial per iteration: the caller falls back)
     TSP_HIP_TRY(hipMemcpyAsync(t->d_chain, t->h_chain, chain_ints * sizeof(int), hipMemcpyHostToDevice, s));
     rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
     if (rc) return rc;
@@ -834,7 +844,7 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
         // k_tabu_post_chain does between two launches of a queued chain, without the write-back, the replica load and the two
         // kernel boundaries (28 + 4.6 + ~8 us of an iteration of ~140 at n = 10 000).  A launch that runs out of sweeps in the
         // middle of an iteration writes its state back and the next launch goes on at chain[1].
-        t->cl_ik_n = count; t->cl_ik_par = par_at;
+        t->cl_ik_n = count; t->cl_ik_par = par_at; t->cl_ik_pairs = pairs; t->cl_ik_ab = ab_at; t->cl_ik_pp = pp_at;
         int done = 0, fell = 0;
         const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, &done, &fell, tabu, iter0, tenure[0]);
         t->cl_ik_n = 0;
@@ -855,6 +865,7 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
             memcpy(&c, res + 8, sizeof c);
             if (obj) obj[k] = c;
             if (improved) improved[k] = res[5];
+            if (trials) trials[k] = res[3];
             if (res[5]) t->h_obj_snap.assign(1, c);
             if (res[0] && tabu->list_valid) {
                 tabu->list_ub += 2;
@@ -931,6 +942,7 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
         memcpy(&c, res + 8, sizeof c);
         if (obj) obj[k] = c;
         if (improved) improved[k] = res[5];
+        if (trials) trials[k] = 1;
         if (res[5]) t->h_obj_snap.assign(1, c);
         if (res[0] && tabu->list_valid) {
             tabu->list_ub += 2;

@@ -84,6 +84,7 @@ def lib():
         L.tsp_dev_tours_tabu_kick.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ip]
         L.tsp_dev_tours_tabu_iteration.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, dp, ip, ip]
         L.tsp_dev_tours_tabu_iterations.argtypes = [vp, vp, C.c_int, C.c_int, ip, ip, C.c_double, dp, dp, ip, ip, ip]
+        L.tsp_dev_tours_tabu_iterations_ex.argtypes = [vp, vp, C.c_int, C.c_int, ip, C.c_int, ip, C.c_double, dp, dp, ip, ip, ip, ip]
         L.tsp_dev_tours_vns_kick.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
         L.tsp_dev_tours_snapshot.argtypes = [vp]
         L.tsp_dev_tours_restore.argtypes = [vp]
@@ -117,7 +118,7 @@ EXPORTED = [
     "tsp_dev_tabu_upload", "tsp_dev_tabu_download", "tsp_dev_tabu_list_info", "tsp_dev_two_opt_tabu", "tsp_dev_perm_cost",
     "tsp_dev_tours_create", "tsp_dev_tours_destroy", "tsp_dev_tours_upload", "tsp_dev_tours_reset",
     "tsp_dev_tours_download", "tsp_dev_tours_run", "tsp_dev_tours_run_engine", "tsp_dev_tours_time_scan", "tsp_dev_tours_best", "tsp_dev_tours_describe", "tsp_dev_tours_device_ms",
-    "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_tabu_iterations", "tsp_dev_tours_vns_kick",
+    "tsp_dev_tours_two_opt", "tsp_dev_tours_two_opt_tabu", "tsp_dev_tours_tabu_kick", "tsp_dev_tours_tabu_iteration", "tsp_dev_tours_tabu_iterations", "tsp_dev_tours_tabu_iterations_ex", "tsp_dev_tours_vns_kick",
     "tsp_dev_tours_snapshot", "tsp_dev_tours_restore", "tsp_dev_host_register", "tsp_dev_host_unregister",
     "tsp_dev_comm_last_error", "tsp_dev_comm_available", "tsp_dev_comm_unique_id", "tsp_dev_comm_init_rank", "tsp_dev_comm_init_all", "tsp_dev_comm_destroy",
     "tsp_dev_comm_info", "tsp_dev_multistart_pack", "tsp_dev_multistart_allreduce", "tsp_dev_multistart_bcast_tour",
@@ -407,6 +408,23 @@ class Tours:
                                                  C.byref(done), C.byref(acc))
         _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
         return rc, done.value, bool(acc.value), best.value, obj[:done.value].copy(), imp[:done.value].copy()
+
+    def tabu_iterations_ex(self, tabu, iter0, tenures, ab, best_obj, time_limit=-1.0):
+        """K = len(tenures) iterations of tabu() in one launch with the kick's trials taken in order from the len(ab) >= K node pairs
+        (tsp_dev_tours_tabu_iterations_ex) -> (status, completed, last_accepted, best_obj', obj [completed], improved [completed],
+        trials [completed])"""
+        K = len(tenures)
+        ten = np.ascontiguousarray(tenures, dtype=np.int32)
+        abv = np.ascontiguousarray(ab, dtype=np.int32)
+        P = abv.size // 2
+        abv = abv.reshape(2 * P)
+        best, obj, imp, tri = C.c_double(best_obj), np.zeros(K), np.zeros(K, dtype=np.int32), np.zeros(K, dtype=np.int32)
+        done, acc = C.c_int(0), C.c_int(0)
+        rc = lib().tsp_dev_tours_tabu_iterations_ex(self._h, tabu._h, iter0, K, _i(ten), P, _i(abv), time_limit, C.byref(best), _d(obj), _i(imp),
+                                                    _i(tri), C.byref(done), C.byref(acc))
+        _check(rc, allow=(OK, TIME_LIMIT_EXCEEDED))
+        d = done.value
+        return rc, d, bool(acc.value), best.value, obj[:d].copy(), imp[:d].copy(), tri[:d].copy()
 
     def tabu_iteration(self, tabu, iter_, tenure, a, b, best_obj, time_limit=-1.0):
         """-> (status, obj, best_obj', improved, accepted): alg_2opt_tabu, incumbent, first kick trial (tabusearch.c:238-309)"""

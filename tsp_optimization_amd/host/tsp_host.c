@@ -21,14 +21,22 @@
 #include "tsp_hip.h"
 
 /* ---- the libc stream, looked ahead ----------------------------------------------------------------------------------------
- * A chain of tabu() iterations (tsp_dev_tours_tabu_iterations) needs the kick's first draws of EVERY iteration before it is
- * queued.  The values of the iterations that then do not run on the device (the chain stops at the first rejected kick) were
- * drawn too early, not wrongly: they go back to the front of this window, and every draw of this file -- URAND(), rand_choice(),
- * the skipped draws of a shard -- takes from the window before it calls random() again.  So the sequence of values the program
- * consumes is the reference's, draw for draw. */
-#define AHEAD_CAP 256
+ * A chain of tabu() iterations (tsp_dev_tours_tabu_iterations_ex) needs the kick's draws of EVERY iteration before it is
+ * launched, and how many of them it takes is known only afterwards (a rejected trial is followed by another, the chain may stop
+ * early).  The values it did not take were drawn too early, not wrongly -- so the generator is put back: libc's state is
+ * remembered before the draws (host_random_mark) and afterwards restored and advanced by exactly the values that were consumed
+ * (host_random_rewind).  Between two chains, and when tabu() returns, random() stands where the reference's run would have left
+ * it: a caller that draws on, or reseeds, sees nothing of the look-ahead.
+ *
+ * The state is copied through the documented switch of state arrays (initstate / setstate, random(3)): setstate() returns the
+ * array that was current, with the generator's position written into its first word (glibc: random_r.c, MAX_TYPES = 5, array
+ * lengths 8 / 32 / 64 / 128 / 256 bytes by type).  The first use checks the round trip (mark, three draws, rewind, the same
+ * three draws); where it does not hold, the fallback is a window of values handed back (host_random_unget) that every draw of
+ * this file -- URAND(), rand_choice(), the skipped draws of a shard -- serves first: the sequence consumed is still the
+ * reference's, only a reseed by the caller in between would not clear it. */
+#define AHEAD_CAP 512
 static long g_ahead[AHEAD_CAP];
-static int g_ahead_n = 0;   /* values waiting, oldest first */
+static int g_ahead_n = 0;   /* values waiting, oldest first (fallback only) */
 
 static long host_random(void) {
     if (g_ahead_n > 0) {
@@ -46,8 +54,51 @@ static void host_random_unget(const long *v, int count) {   /* v[0] is the next 
     g_ahead_n += count;
 }
 int tsp_host_random_lookahead(void) { return g_ahead_n; }
+
+typedef struct { char *where; size_t len; char copy[256]; } random_mark;
+static char g_scratch_state[256];
+static int g_mark_ok = -1;   /* -1 not tried, 0 the round trip does not hold here, 1 it does */
+
+static int random_mark_take(random_mark *m) {
+    static const size_t len_of[5] = {8, 32, 64, 128, 256};
+    char *cur = initstate(1u, g_scratch_state, sizeof g_scratch_state);   /* parks the generator on a scratch array; cur = the caller's */
+    if (!cur) return 0;
+    unsigned info;
+    memcpy(&info, cur, sizeof info);
+    m->where = cur; m->len = len_of[info % 5u];
+    memcpy(m->copy, cur, m->len);
+    return setstate(cur) != NULL;
+}
+static int random_mark_back(const random_mark *m, long advance) {
+    if (!initstate(1u, g_scratch_state, sizeof g_scratch_state)) return 0;
+    memcpy(m->where, m->copy, m->len);
+    if (!setstate(m->where)) return 0;
+    for (long k = 0; k < advance; k++) (void)random();
+    return 1;
+}
+static int host_random_mark(random_mark *m) {
+    if (g_mark_ok < 0) {
+        random_mark t;
+        long a[3], b[3];
+        g_mark_ok = 0;
+        if (random_mark_take(&t)) {
+            for (int k = 0; k < 3; k++) a[k] = random();
+            if (random_mark_back(&t, 1)) {
+                b[0] = a[0]; b[1] = random(); b[2] = random();
+                const int same = a[1] == b[1] && a[2] == b[2];
+                if (random_mark_back(&t, 0) && random() == a[0] && same && random_mark_back(&t, 0)) g_mark_ok = 1;
+            }
+        }
+    }
+    return g_mark_ok == 1 && g_ahead_n == 0 && random_mark_take(m);
+}
+/* the generator back to the mark and `consumed` values on; raw[0 .. drawn) are the values drawn since the mark (fallback: handed back) */
+static void host_random_rewind(const random_mark *m, int marked, const long *raw, int drawn, int consumed) {
+    if (marked && random_mark_back(m, consumed)) return;
+    host_random_unget(raw + consumed, drawn - consumed);
+}
 #undef URAND
-#define URAND() (((double)host_random()) / RAND_MAX)   /* include/utility.h:36 on the looked-ahead stream */
+#define URAND() (((double)host_random()) / RAND_MAX)   /* include/utility.h:36 (the fallback's window first) */
 
 #define GRASP_ITER_TIME_LIM 120 /* src/heuristics.c:11 */
 #define TABU_CHAIN 64           /* most iterations of tabu() queued per wait for the device */
@@ -578,6 +629,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
      * twelve is rejected, chains run ten iterations on average; one in six at n = 299) */
     double mean_run = 8.0;
     const int trace = getenv("TSP_HOST_TRACE") != NULL;
+    /* iterations inside the launch, the kick's further trials included (the default), or queued launches with one trial each */
+    const int in_kernel = !(getenv("TSP_TABU_INKERNEL") && atoi(getenv("TSP_TABU_INKERNEL")) == 0);
     struct timeval tl0, tl1;
     gettimeofday(&tl0, 0);
     long long st_chains = 0, st_queued = 0, st_done = 0, st_single = 0, st_retrials = 0;   /* TSP_HOST_STATS=1: printed at the end */
@@ -594,8 +647,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         if (policy == 2)
             for (int k = 0; k < K - 1; k++)
                 if (iter + k == 1 || (iter + k) % 100 == 0) { K = k + 1; break; }
-        int tenures[64], ab[128], improved[64] = {0};
-        long raw[128];
+        int tenures[64], ab[256], improved[64] = {0}, trials[64];
+        long raw[256];
         double objs[64];
         {
             int ten = tenure, ris = rising;
@@ -604,21 +657,34 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
                 tabu_policy_step(policy, iter + k, &ten, &ris, lo, hi, 0);
             }
         }
-        /* the first draws of every iteration's kick (:264-265), in the order the iterations would make them */
-        for (int k = 0; k < 2 * K; k++) { raw[k] = host_random(); ab[k] = (int)((((double)raw[k]) / RAND_MAX) * n); }
-        int completed = 0, accepted = 0;
+        /* The draws of the kicks (:264-265, and :262-287 for the trials that follow a rejected one), in the order the iterations
+         * would make them: K first trials and a reserve for the further ones (one first trial in twelve is rejected at n = 10 000,
+         * one in six at n = 299).  With the iterations inside the launch the device takes the pairs in order, further trials
+         * included, and reports how many each iteration took; what it did not take goes back to the front of the window. */
+        const int P = in_kernel ? (K + K / 3 + 4 > 128 ? 128 : K + K / 3 + 4) : K;
+        random_mark mark;
+        const int marked = host_random_mark(&mark);
+        for (int k = 0; k < 2 * P; k++) { raw[k] = host_random(); ab[k] = (int)((((double)raw[k]) / RAND_MAX) * n); }
+        int completed = 0, accepted = 0, consumed = 0;
         pthread_mutex_lock(&g_lock);
-        rc = tsp_dev_tours_tabu_iterations(t, tb, iter, K, tenures, ab, limit_of(inst), &best_obj, objs, improved, &completed, &accepted);   /* :238-249, :262-309 */
+        if (in_kernel)
+            rc = tsp_dev_tours_tabu_iterations_ex(t, tb, iter, K, tenures, P, ab, limit_of(inst), &best_obj, objs, improved, trials, &completed, &accepted);   /* :238-249, :262-309 */
+        else
+            rc = tsp_dev_tours_tabu_iterations(t, tb, iter, K, tenures, ab, limit_of(inst), &best_obj, objs, improved, &completed, &accepted);
         pthread_mutex_unlock(&g_lock);
         if (rc < 0) dev_fail("tsp_dev_tours_tabu_iterations", rc);
         st_chains++; st_queued += K; st_done += completed;
-        for (int k = 0; k < completed; k++) if (improved[k]) have_best = 1;
+        for (int k = 0; k < completed; k++) {
+            if (improved[k]) have_best = 1;
+            consumed += in_kernel ? trials[k] : 1;
+            if (in_kernel) st_retrials += trials[k] - 1;
+        }
         if (rc > 0 && completed < K && improved[completed]) have_best = 1;   /* cut short by the time limit: the incumbent is updated before the status is looked at (:241-249, :255) */
-        if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); host_random_unget(raw + 2 * completed, 2 * (K - completed)); break; }
+        if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); host_random_rewind(&mark, marked, raw, 2 * P, 2 * consumed); break; }
         if (completed == 0) {
             /* the chain did not apply, or its first iteration could not be finished on the device: this iteration the one-wait
              * way, with the draws it has; the later iterations' draws wait for their turn */
-            host_random_unget(raw + 2, 2 * (K - 1));
+            host_random_rewind(&mark, marked, raw, 2 * P, 2);
             double obj = 0.0;
             int imp = 0;
             pthread_mutex_lock(&g_lock);
@@ -628,14 +694,15 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
             if (rc < 0) dev_fail("tsp_dev_tours_tabu_iteration", rc);
             if (rc) { status = rc; LOG_I("2-opt move returned status %d", rc); break; }
             completed = 1; st_single++;
+            objs[0] = obj;
         } else {
-            host_random_unget(raw + 2 * completed, 2 * (K - completed));
+            host_random_rewind(&mark, marked, raw, 2 * P, 2 * consumed);
         }
         if (trace) {   /* TSP_HOST_TRACE=1: one line per iteration (a divergence between two runs shows at its first iteration) */
             if (iter == 1) fprintf(stderr, "[tabu-trace] start obj %.0f\n", obj0);
             for (int k = 0; k < completed; k++)
-                fprintf(stderr, "[tabu-trace] iter %d tenure %d a %d b %d obj %.0f%s\n", iter + k, tenures[k], ab[2 * k], ab[2 * k + 1],
-                        st_single && completed == 1 && k == 0 ? -1.0 : objs[k], k == completed - 1 ? (accepted ? " +" : " -") : " +");
+                fprintf(stderr, "[tabu-trace] iter %d tenure %d trials %d obj %.0f%s\n", iter + k, tenures[k], in_kernel && !st_single ? trials[k] : 1,
+                        objs[k], k == completed - 1 ? (accepted ? " +" : " -") : " +");
         }
         mean_run = 0.75 * mean_run + 0.25 * completed;
         /* every completed iteration but the last had its kick accepted (the chain stops at a rejection) */
