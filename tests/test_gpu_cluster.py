@@ -531,3 +531,35 @@ def test_chain_with_the_kicks_further_trials_on_the_device_equals_the_replay_one
     for x in (t1, t2, tb1, tb2):
         x.close()
     inst.close()
+
+
+def test_a_give_up_in_the_middle_of_a_chain_goes_on_from_the_incumbent(eng, ctx, monkeypatch):
+    """A workgroup that stops answering after two iterations of a chain (test hook TSP_CLUSTER_DEBUG & 2048): the launch is lost
+    with the tours of its completed iterations, the incumbent and the stamps are not -- tsp_dev_tours_tabu_iterations_ex reports
+    the completed iterations, leaves the incumbent as the tour to go on from, and the next calls work (other engine while the
+    back-off lasts)."""
+    monkeypatch.setenv("TSP_CLUSTER_DEBUG", "2048")
+    monkeypatch.setenv("TSP_CLUSTER_SPIN_MS", "5")
+    xy, wt = load_instance("pr1002")
+    n = len(xy)
+    ctx = eng.Context(0)                      # a context of its own: the back-off after the give-up lives in it
+    inst = eng.Instance(ctx, xy, wt, 1)
+    _, succ0, obj0 = O.greedy(xy, wt)
+    rng = np.random.default_rng(3)
+    K = 6
+    ab = rng.integers(0, n, size=(K + 4, 2)).astype(np.int32)
+    t, tb = eng.Tours(inst, 1), eng.Tabu(inst)
+    t.upload(succ0, obj0)
+    rc, done, last_acc, best, obj, imp, tri = t.tabu_iterations_ex(tb, 1, [30] * K, ab, float("inf"))
+    assert rc == 0 and done == 2 and last_acc and imp[0] == 1 and best == min(obj)
+    assert "goes on from the incumbent" in eng.lib().tsp_dev_last_error().decode()
+    s, o, _ = t.download()
+    assert O.is_tour(s[0]) and O.succ_cost(xy, wt, s[0]) == best        # the incumbent is the tour now
+    # the search goes on: the next iterations run (one by one: the chain is refused while the back-off lasts)
+    rc, done2, _, best2, obj2, _, _ = t.tabu_iterations_ex(tb, 3, [30] * 2, ab[4:], best)
+    assert rc == 0
+    if done2 == 0:
+        rc, o3, best2, improved, acc = t.tabu_iteration(tb, 3, 30, int(ab[4, 0]), int(ab[4, 1]), best)
+        assert rc == 0 and o3 <= O.succ_cost(xy, wt, s[0])
+    assert best2 <= best
+    t.close(); tb.close(); inst.close(); ctx.close()

@@ -86,6 +86,7 @@ struct tsp_dev_ctx {
     // `cl_skip` AUTO decisions go to the other engines; the back-off doubles with every further give-up (64 .. 4096 calls)
     int cl_skip = 0, cl_backoff = 0;
     long long cl_giveups = 0;
+    long long cl_chain_losses = 0;   // give-ups in the middle of a chain of tabu() iterations (the search went on from the incumbent)
 };
 
 namespace tsp { struct NodeRec; }

@@ -1621,6 +1621,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         if (!kicked) a.chain[0] = 1;   // rejected (and no pair left to try): the host draws the next trial (tabusearch.c:262-287)
                     }
                     ck += 1;
+                    if ((a.dbg & 2048) && c == 1 && ck >= 2) return;   // test hook: a workgroup stops answering in the middle of a chain
                     kpp = a.chain_pairs > 0 ? ptaken + 1 : ck;
                     if (kicked && ck < a.chain_n) {   // the next iteration's alg_2opt_tabu, on the kicked tour
                         done = 0;

@@ -878,10 +878,23 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
             // The exchange gave up.  In the launch's first exchanges nothing of the search state has been touched (the list may have
             // two entries more than stamps: a superset is what it has to be): the host takes the other path.  Later -- a workgroup
             // that had been resident stopped answering in the middle of a chain -- the kicks of the completed iterations are in
-            // the stamps while the tour in HBM is the one the launch started from: that is not recoverable here.
+            // the stamps while the tour in HBM is the one the launch started from.
             if (nc == 0) { if (tabu->list_valid) tabu->list_ub += 2; return TSP_OK; }
-            tsp::set_last_error("k_cluster_two_opt: the exchange gave up in the middle of a chain of tabu() iterations", hipErrorLaunchFailure, __FILE__, __LINE__);
-            return TSP_DEV_E_HIP;
+            // Degraded, not aborted: the incumbent (tour and cost) and the stamps are intact, so the search goes on FROM THE
+            // INCUMBENT -- a valid tabu search, no longer the reference's trajectory (which a device shared to the point of a
+            // give-up has lost anyway: its runs end on the wall clock).  The event is counted and left in tsp_dev_last_error().
+            tsp::set_last_error("k_cluster_two_opt: the exchange gave up in the middle of a chain of tabu() iterations; the search goes on from the incumbent",
+                                hipErrorLaunchFailure, __FILE__, __LINE__);
+            t->inst->ctx->cl_chain_losses += 1;
+            memcpy(best_obj, t->h_chain + 2, sizeof(double));
+            if (!t->h_obj_snap.empty()) {
+                const int rc2 = tsp_grid_snapshot(t, /*restore=*/true);
+                if (rc2) return rc2;
+            }
+            tabu->list_valid = false;   // (entries may be missing for stamps of the lost iterations: rebuilt by a scan before the next use)
+            *completed = nc;
+            if (last_accepted) *last_accepted = 1;
+            return TSP_OK;
         }
         tabu->last_run_list = true;
         memcpy(best_obj, t->h_chain + 2, sizeof(double));
