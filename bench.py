@@ -769,7 +769,7 @@ def main():
         res["live_stamps"] = live
         # tabu() itself (tabusearch.c:188-320, step policy) through the C host: tsp_host_tabu of libtsp_host.so keeps tour, stamps and
         # incumbent on the device, draws on the host's libc stream, and queues chains of iterations per wait for the device
-        # (tsp_dev_tours_tabu_iterations; a chain stops where a kick's first trial is rejected).  Rate = iterations / the seconds the
+        # (tsp_dev_tours_tabu_iterations_ex: the iterations of a chain run inside one launch).  Rate = iterations / the seconds the
         # call spent in its iteration loop (tsp_host_last_driver_loop_seconds): the initial HEU_2opt_greedy_iter (:200) is not in it.
         import ctypes as C
         H, _Instance = host_lib()
@@ -791,11 +791,17 @@ def main():
         iters = 1500
         tabu_rate(None, 60)                      # warm
         chained = tabu_rate(None, iters)
+        os.environ["TSP_TABU_INKERNEL"] = "0"
+        queued = tabu_rate(None, iters)
+        os.environ.pop("TSP_TABU_INKERNEL", None)
         single = tabu_rate(1, iters)
         res["tabu_iterations_on_resident_state"] = dict(
-            chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123, chains of iterations queued per "
-                            "wait for the device (length adapted to how far the chains run)",
-            one_iteration_per_wait=single, same_incumbent_both_ways=bool(chained["incumbent"] == single["incumbent"]))
+            chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123: chains of up to 64 iterations "
+                            "INSIDE one CLUSTER launch (incumbent, the kick's trials, the kick and the next descent in the kernel; "
+                            "tsp_dev_tours_tabu_iterations_ex)",
+            queued_launches=dict(queued, what="TSP_TABU_INKERNEL=0: the launches of a chain queued back to back, one small kernel between two"),
+            one_iteration_per_wait=single,
+            same_incumbent_all_ways=bool(chained["incumbent"] == single["incumbent"] == queued["incumbent"]))
         H.tsp_host_shutdown()
         out["alg_2opt_tabu_with_a_list"] = res
 
