@@ -233,7 +233,7 @@ int tsp_dev_tours_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter
  * `pairs` (count <= pairs <= 128) node pairs in the order tabu() would draw them, and the iterations take them in that order --
  * iteration iter0 + k starts with the pair after the last one iteration iter0 + k - 1 took, and a rejected trial is followed by
  * the next pair, all inside the launch (the CLUSTER engine's tabu variant runs the iterations itself: incumbent, trials, kick
- * and the next descent on the replicas).  trials[k] = pairs iteration k took (>= 1); the caller has consumed
+ * and the next descent on the replicas).  trials[k] = pairs iteration k took (0 when the earlier iterations had used them all up: no trial was made); the caller has consumed
  * sum(trials[0 .. *completed - 1]) pairs and serves the rest of its look-ahead first.  *last_accepted = 0 only when the pairs ran
  * out in the middle of an iteration's trials: the caller draws on (tsp_dev_tours_tabu_kick).  Everything else as above.  Where
  * the iterations cannot run inside a launch (TSP_TABU_INKERNEL=0, another engine) *completed = 0 and the caller takes

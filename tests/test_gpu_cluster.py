@@ -528,6 +528,12 @@ def test_chain_with_the_kicks_further_trials_on_the_device_equals_the_replay_one
     ab2[1] = (4, 4); ab2[2] = (5, 5)
     rc, done, last_acc, best3, obj3, imp3, tri3 = t2.tabu_iterations_ex(tb2, 1 + K, [30, 30, 30], ab2, best2)
     assert rc == 0 and done == 2 and not last_acc and list(tri3) == [1, 2]
+    # ... and when they run out exactly at an iteration's end, the next iteration has its descent and no trial at all
+    assert t2.tabu_kick(tb2, 11, 600, 2 + K, 30)
+    ab3 = rng.integers(0, n, size=(3, 2)).astype(np.int32)
+    ab3[1] = (6, 6)
+    rc, done, last_acc, best4, obj4, imp4, tri4 = t2.tabu_iterations_ex(tb2, 3 + K, [30, 30, 30], ab3, best3)
+    assert rc == 0 and done == 3 and not last_acc and list(tri4) == [1, 2, 0]
     for x in (t1, t2, tb1, tb2):
         x.close()
     inst.close()

@@ -229,28 +229,32 @@ def test_vns_rounds_match_oracle(host, monkeypatch, name, rounds, fs):
     assert eo <= o1 and h.obj == O.succ_cost(h.xy, h.wt, h.succ)
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2])
-def test_tabu_iterations_match_oracle(host, policy):
-    """tabu() (tabusearch.c:188-320) with the iteration cap: device-resident stamps, host RNG, same kicks."""
+@pytest.mark.parametrize("policy,iters", [(0, 120), (1, 120), (2, 120), (1, 1500), (0, 1500)])
+def test_tabu_iterations_match_oracle(host, policy, iters):
+    """tabu() (tabusearch.c:188-320) with the iteration cap: device-resident stamps, host RNG, same kicks.  The long runs go
+    through dozens of chains of 64 iterations inside one launch each -- kicks whose first trials are rejected (one in six at this
+    size), pairs that run out in the middle of a chain, the tenure changing with every iteration (linear policy)."""
     h = HostInstance("pr299")
     h.c.params.time_limit = 600
     O.srandom(123)
-    rc = host.tsp_host_tabu(C.byref(h.c), policy, 120)
+    rc = host.tsp_host_tabu(C.byref(h.c), policy, iters)
     s1, o1 = _initial(h)
     O.srandom(123)
-    es, eo, moves = O.tabu(h.xy, h.wt, s1, o1, 120, policy)
+    es, eo, moves = O.tabu(h.xy, h.wt, s1, o1, iters, policy)
     assert rc == 0 and h.obj == eo and (h.succ == es).all() and moves > 0
     assert h.obj == O.succ_cost(h.xy, h.wt, h.succ)
 
 
-@pytest.mark.parametrize("policy,chain", [(0, "1"), (0, "5"), (1, "32"), (2, "7"), (2, "64")])
-def test_tabu_chains_give_the_oracles_search_and_leave_the_libc_stream_where_it_leaves_it(host, policy, chain, monkeypatch):
-    """tsp_host_tabu queues TSP_TABU_CHAIN iterations per wait for the device (tsp_dev_tours_tabu_iterations) and therefore draws
-    every iteration's first kick nodes before the chain runs; a chain stops at the first rejected kick (at n = 299 about one
-    trial in six is rejected: shared nodes, tabu edges) and the draws of the iterations that did not run go back to the head
-    of the stream.  Whatever the chain length: the oracle's incumbent after 150 iterations (tour, cost) -- and the NEXT value
-    of libc's random() after the run equals the one after the oracle's run, i.e. exactly the reference's number of draws was
-    consumed, in its order (the policy's own draws, random policy, included)."""
+@pytest.mark.parametrize("policy,chain,in_kernel", [(0, "1", 1), (0, "5", 1), (1, "32", 1), (2, "7", 1), (2, "64", 1), (1, "64", 1), (1, "32", 0), (0, "64", 0)])
+def test_tabu_chains_give_the_oracles_search_and_leave_the_libc_stream_where_it_leaves_it(host, policy, chain, in_kernel, monkeypatch):
+    """tsp_host_tabu hands the device TSP_TABU_CHAIN iterations at a time -- inside one launch with the kick's further trials
+    (tsp_dev_tours_tabu_iterations_ex) or, TSP_TABU_INKERNEL=0, as launches queued back to back that stop at the first rejected
+    kick -- and therefore draws the kicks' nodes before the chain runs (at n = 299 about one trial in six is rejected: shared
+    nodes, tabu edges).  What the device did not take was drawn too early: the generator is rewound to it.  Whatever the chain
+    length and form: the oracle's incumbent after 150 iterations (tour, cost) -- and the NEXT value of libc's random() after
+    the run equals the one after the oracle's run, i.e. exactly the reference's number of draws was consumed, in its order (the
+    policy's own draws, random policy, included), and nothing is held back in the library."""
+    monkeypatch.setenv("TSP_TABU_INKERNEL", str(in_kernel))
     monkeypatch.setenv("TSP_TABU_CHAIN", chain)
     libc = C.CDLL(None)
     libc.random.restype = C.c_long

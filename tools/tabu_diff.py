@@ -21,8 +21,12 @@ out = {}
 for mode in ("1", "0"):
     env = dict(os.environ, TSP_TABU_INKERNEL=mode, TSP_HOST_TRACE="1")
     p = subprocess.run([sys.executable, __file__, "--child", name, policy, iters], env=env, capture_output=True, text=True)
-    lines = [l.split(" trials")[0] + " obj" + l.split(" obj")[1] for l in p.stderr.splitlines() if l.startswith("[tabu-trace] iter")]
+    lines = [l.split(" trials")[0] + " obj " + l.split(" obj ")[1].split()[0] for l in p.stderr.splitlines() if l.startswith("[tabu-trace] iter")]   # (iteration, tenure, cost)
     out[mode] = (lines, p.stdout.strip(), [l for l in p.stderr.splitlines() if l.startswith("[tabu-trace] iter")])
+    chains = [l for l in p.stderr.splitlines() if l.startswith("[tabu-chain]")]
+    want = int(os.environ.get("TABU_DIFF_NEAR", "0"))
+    if want:
+        print("  chains near iteration %d:" % want, [l[13:] for l in chains if abs(int(l.split("from ")[1].split(":")[0]) - want) < 140])
     print("inkernel=%s: %d trace lines, %s" % (mode, len(lines), p.stdout.strip()))
 a, b = out["1"][0], out["0"][0]
 for k, (x, y) in enumerate(zip(a, b)):

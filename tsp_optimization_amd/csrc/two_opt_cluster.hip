@@ -1512,6 +1512,10 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             for (int p = tid; p < n; p += kClThreads) a.snap[p] = a.gid[(int)order[p]];
                         }
                         int2 *list = const_cast<int2 *>(a.tabu_list);
+                        if (kpp >= npairs) {   // the earlier iterations' further trials have used the pairs up: no trial, the caller draws on
+                            if (tid == 0) { s_kick[0] = 0; s_kick[3] = 0; s_kick[4] = 0; s_kick[5] = 0; s_kick[6] = kpp; }
+                            __syncthreads();
+                        } else
                         for (int pp = kpp;; ++pp) {   // the trials of this iteration's kick, in the order tabu() draws them
                             const int ka = a.chain_ab[4 * pp], kb = a.chain_ab[4 * pp + 1];
                             const int ia = a.chain_ab[4 * pp + 2], ib = a.chain_ab[4 * pp + 3];   // the same two nodes inside the replica

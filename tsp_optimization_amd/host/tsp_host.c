@@ -700,6 +700,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         }
         if (trace) {   /* TSP_HOST_TRACE=1: one line per iteration (a divergence between two runs shows at its first iteration) */
             if (iter == 1) fprintf(stderr, "[tabu-trace] start obj %.0f\n", obj0);
+            fprintf(stderr, "[tabu-chain] from %d: %d iterations asked, %d pairs, %d completed, %d pairs taken, last kick %s\n", iter, K, P, completed,
+                    consumed, accepted ? "accepted" : "rejected");
             for (int k = 0; k < completed; k++)
                 fprintf(stderr, "[tabu-trace] iter %d tenure %d trials %d obj %.0f%s\n", iter + k, tenures[k], in_kernel && !st_single ? trials[k] : 1,
                         objs[k], k == completed - 1 ? (accepted ? " +" : " -") : " +");
