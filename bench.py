@@ -791,9 +791,13 @@ def main():
         iters = 1500
         tabu_rate(None, 60)                      # warm
         chained = tabu_rate(None, iters)
+        H.tsp_host_shutdown()                    # (switches are read when a device instance is made: drop the cached one)
         os.environ["TSP_TABU_INKERNEL"] = "0"
+        tabu_rate(None, 60)
         queued = tabu_rate(None, iters)
         os.environ.pop("TSP_TABU_INKERNEL", None)
+        H.tsp_host_shutdown()
+        tabu_rate(None, 60)
         single = tabu_rate(1, iters)
         res["tabu_iterations_on_resident_state"] = dict(
             chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123: chains of up to 64 iterations "

@@ -58,6 +58,3 @@ print("  own work outside the exchange phase (tests + scan + arg-min + move) per
 se = tail_extra[used, 0] / 100.0 / steps
 order_ = np.argsort(-se)
 print("  list side effects per workgroup (thread 64): highest five", [(int(i), round(float(se[i]), 2)) for i in order_[:5]])
-cnt6 = a_tail[used, 6]
-print("  thread 64, per workgroup and sweep: entries looked at %.3f, of them answered from the registers (same neighbours) %.3f, skipped as zero %.3f"
-      % ((cnt6 / steps)[1:].mean(), (tail_extra[used, 1] / steps)[1:].mean(), (tail_extra[used, 3] / steps)[1:].mean()))
