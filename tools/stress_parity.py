@@ -109,6 +109,71 @@ def _run(seed, cases, ctx, verbose, max_n):
             ok = _chk(ok, 98, (s == ts).all() and o == to and (st["sweeps"], st["evals"], st["moves"]) == (tst["sweeps"], tst["evals"], tst["moves"]))
             ok = _chk(ok, 99, (tb.download() == exp).all() and tb.list_info()[1])
             tb.close()
+        if 8 <= n <= 300 and wt in (O.EUC_2D, O.ATT, O.CEIL_2D):
+            # a chain of tabu() iterations INSIDE one launch (tsp_dev_tours_tabu_iterations_ex) from a dense random tabu list: random
+            # tenures (one per iteration), random kick pairs with rejected ones among them (a == b, neighbours, tabu edges), against
+            # the oracle's alg_2opt_tabu + a restatement of the kick's trials (tabusearch.c:262-309) iteration by iteration
+            it0, K = int(rng.integers(1, 30)), int(rng.integers(2, 9))
+            tens = [int(rng.integers(0, 12)) for _ in range(K)]
+            P = K + int(rng.integers(0, 6))
+            ab = rng.integers(0, n, size=(P, 2)).astype(np.int32)
+            for q in range(P):
+                r = rng.random()
+                if r < 0.15: ab[q, 1] = ab[q, 0]
+            stamps = np.zeros(n * (n - 1) // 2, dtype=np.int32)
+            up = lambda a, b: min(a, b) * n + max(a, b) - (min(a, b) + 1) * (min(a, b) + 2) // 2
+            for _ in range(int(rng.choice([0, n // 2, 2 * n]))):
+                a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+                if rng.random() < 0.4: b = int(tour[a])
+                if a != b: stamps[up(a, b)] = int(rng.integers(1, it0 + 1))
+            exp = stamps.copy()
+            cur, curo = np.array(tour, dtype=np.int32), float(cost)
+            best, objs, trials, p, stopped = float("inf"), [], [], 0, False
+
+            def is_tabu(a, b, itn, ten):      # check_tenure, :83-92
+                v = exp[up(a, b)]
+                if v == 0: return False
+                if itn - v > ten: exp[up(a, b)] = 0; return False
+                return True
+            for k in range(K):
+                itn, ten = it0 + k, tens[k]
+                _, cur, curo, _, _, _ = O.two_opt_best(xy, wt, cur, integer_cost=ic, tabu=exp, iter_=itn, tenure=ten)
+                cur = np.array(cur, dtype=np.int32)
+                best = min(best, curo)
+                objs.append(curo)
+                used, acc = 0, False
+                while p < P and not acc:
+                    a, b = int(ab[p, 0]), int(ab[p, 1]); p += 1; used += 1
+                    a1, b1 = int(cur[a]), int(cur[b])
+                    if a == b or a1 == b or b1 == a: continue
+                    if not is_tabu(a, a1, itn, ten) and not is_tabu(b, b1, itn, ten) and not is_tabu(a, b, itn, ten) and not is_tabu(a1, b1, itn, ten):
+                        acc = True
+                        path, v = [], a1                       # a1 ... b along the tour, reversed (utility.c:708-717)
+                        while True:
+                            path.append(v)
+                            if v == b: break
+                            v = int(cur[v])
+                        cur[a] = b
+                        for q in range(len(path) - 1, 0, -1): cur[path[q]] = path[q - 1]
+                        cur[a1] = b1
+                        exp[up(a, a1)] = itn; exp[up(b, b1)] = itn
+                trials.append(used)
+                if not acc: stopped = True; break
+            t, tb = E.Tours(inst, 1), E.Tabu(inst)
+            t.upload(np.array(tour, dtype=np.int32), float(cost))
+            tb.upload(stamps)
+            rc, done, last_acc, b2, o2, _, tr2 = t.tabu_iterations_ex(tb, it0, tens, ab, float("inf"))
+            if done > 0:                                        # (0: the chain does not apply to this case -- nothing to compare)
+                ok = _chk(ok, 131, rc == 0 and done == len(objs) and list(o2) == objs and list(tr2) == trials and b2 == best and bool(last_acc) == (not stopped))
+                sd, od, _ = t.download()
+                ok = _chk(ok, 133, (sd[0] == cur).all())
+                got = tb.download()
+                if verbose and not (got == exp).all():
+                    w = np.nonzero(got != exp)[0]
+                    print("  stamps differ at %d entries; first: index %d device %d oracle %d (initial %d); chain from iteration %d, tenures %s, trials %s"
+                          % (len(w), w[0], got[w[0]], exp[w[0]], stamps[w[0]], it0, tens, trials))
+                ok = _chk(ok, 134, (got == exp).all())
+            t.close(); tb.close()
         if c % 3 == 0 and n >= 8:
             # a batch of three or eight tours through the engine the library picks, and one GRASP tour on the oracle's URAND stream
             nt = 8 if n <= 200 else 3   # eight tours: the grid divides by XCD (a tour's workgroups from one XCD)

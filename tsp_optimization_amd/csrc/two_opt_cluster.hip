@@ -1494,7 +1494,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     // iter and tenure are constant), across iterations it is not (the tenure changes).  So at this boundary every
                     // workgroup writes its XCD's dirty lines back BEFORE it publishes (release), and drops what it holds AFTER the
                     // exchange (acquire): whatever was cleared in this iteration is in memory before anybody reads a stamp for the
-                    // next one, and the stamps of the kick are written by each workgroup into its own L2 (the same value by all).
+                    // next one, and the stamps of the kick are written by each workgroup into its own L2 (the same value by all) and
+                    // written back at once.
                     const int npairs = a.chain_pairs > 0 ? a.chain_pairs : a.chain_n;
                     int *res = a.chain + 4 + 10 * ck;
                     int *s_kick = reinterpret_cast<int *>(s_chunk);   // {accepted, have0, have1, a1, b1, entries appended, pair taken}: the cost's chunks are through
@@ -1594,7 +1595,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     const int ka1 = kicked ? key_i(*s_win_k) : 0, kb1 = kicked ? key_j(*s_win_k) : 0;
                     if (kicked) {
                         const int pa = (int)pos[ia], pb = (int)pos[ib];
-                        if (tid == 0) { a.tabu[udir_pos(a.chain_ab[4 * ptaken], ka1, n)] = cur_iter; a.tabu[udir_pos(a.chain_ab[4 * ptaken + 1], kb1, n)] = cur_iter; }   // :306-309
+                        if (tid == 0) {   // :306-309
+                            a.tabu[udir_pos(a.chain_ab[4 * ptaken], ka1, n)] = cur_iter; a.tabu[udir_pos(a.chain_ab[4 * ptaken + 1], kb1, n)] = cur_iter;
+                            // ... and out of this XCD's L2 at once: with tenure 0 the stamp expires in the very iteration that
+                            // follows, another XCD's workgroup clears it (a dirty 0 there), and this copy must not be the one that
+                            // reaches memory last (found by the randomised chains of tools/stress_parity.py)
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        }
                         if constexpr (INT) {   // the running cost (exact: integer terms)
                             const int a1i = (int)order[pa + 1 == n ? 0 : pa + 1], b1i = (int)order[pb + 1 == n ? 0 : pb + 1];
                             run_obj += cl_dist<WT, INT, CT>(coord, ia, ib) + cl_dist<WT, INT, CT>(coord, a1i, b1i) -
