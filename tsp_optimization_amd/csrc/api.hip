@@ -2,6 +2,7 @@
 #include "tsp_internal.hpp"
 
 #include <stdlib.h>
+#include <mutex>
 
 #include <algorithm>
 #include <time.h>
@@ -180,25 +181,33 @@ extern "C" {
 
 const char *tsp_dev_last_error(void) { return tsp::g_last_error; }
 
-int tsp_dev_count(void) {
-    int c = 0;
-    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
-    return c;
-}
-
 namespace {
 // The HIP runtime's initialisation reseeds libc's random() generator (tools/rng_probe.py: srandom(123), a first device call,
 // random() -> not the value the seed promises, and a different one in every process).  The reference's drivers seed once in
 // main and draw with random() / rand() throughout (utility.h:36), and tabu() / HEU_VNS begin with device work here
 // (HEU_2opt_greedy_iter) before their first draw: the process's generator is parked on a scratch state while the runtime comes
 // up and put back exactly as the caller left it.
+// (One keeper at a time, process-wide: tsp_host_population_gpus opens a context per GPU from a thread each, and two interleaved
+// switches would leave the process on one of the scratch arrays.  The scratch array is static for the same reason: libc never
+// points into a dead stack frame.)
+std::mutex g_open_mutex;
 struct LibcRandomKeeper {
-    char scratch[256];
+    std::lock_guard<std::mutex> lock;
     char *old;
-    LibcRandomKeeper() { old = initstate(1u, scratch, sizeof scratch); }
+    LibcRandomKeeper() : lock(g_open_mutex) {
+        static char scratch[256];
+        old = initstate(1u, scratch, sizeof scratch);
+    }
     ~LibcRandomKeeper() { if (old) (void)setstate(old); }
 };
 }  // namespace
+
+int tsp_dev_count(void) {
+    LibcRandomKeeper keep_libc_random;   // (this may be the process's first HIP call)
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
 
 int tsp_dev_open(int device, tsp_dev_ctx **out) {
     if (!out) return TSP_DEV_E_ARG;
