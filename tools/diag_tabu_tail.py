@@ -58,3 +58,6 @@ print("  own work outside the exchange phase (tests + scan + arg-min + move) per
 se = tail_extra[used, 0] / 100.0 / steps
 order_ = np.argsort(-se)
 print("  list side effects per workgroup (thread 64): highest five", [(int(i), round(float(se[i]), 2)) for i in order_[:5]])
+cnt = a_tail[used]
+print("  thread 64 of the workgroups >= 1, per sweep: entries loaded %.3f, answered from the registers %.3f, skipped as zero %.3f"
+      % ((cnt[1:, 6] / steps).mean(), (cnt[1:, 9] / steps).mean(), (cnt[1:, 11] / steps).mean()))

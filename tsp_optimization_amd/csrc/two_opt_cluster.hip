@@ -726,6 +726,16 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     int2 tl_e = make_int2(0, 0);
     int tl_iu = 0, tl_iv = 0;
     bool tl_have = false;
+    // ... and what that entry contributed in the last sweep, with the four tour neighbours it was computed from.  Inside one
+    // iteration of tabu() nothing becomes tabu (stamps are written by kicks only) and what has expired stays expired: an entry
+    // whose neighbours are the same contributes the same, and an entry whose stamp is zero stays out -- no load at all.
+    // tl_state: 0 look, 1 the stamp is zero (until the next kick), 2 live: tl_cnt / tl_edge hold for the neighbours tl_nb0 / tl_nb1
+    int tl_state = 0, tl_cnt = 0;
+    unsigned tl_nb0 = 0, tl_nb1 = 0;
+    bool tl_edge = false;
+#ifdef TSP_STAMPS
+    unsigned tl_n_skip = 0, tl_n_hit = 0, tl_n_full = 0;
+#endif
     int tl_m = 0;   // entries of the list (the count runs on past the capacity, as on the host): read once, kept up with the kicks of a chain
     if constexpr (TABU) tl_m = *a.tabu_list_n;
     bool leave = false;   // FIRST: hand the descent to the other variant of this kernel (the host launches it)
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
         double bd = (SORTED && BEST) ? b0 : 0.0;   // every lane starts from the bound; a lane without a pair keeps key == kNoKey
         u64 key = kNoKey;
         unsigned ipair = 0;
-        const int slot_cur = TABU ? (int)(sweeps % 3) : 0, slot_prev = slot_cur == 0 ? 2 : slot_cur - 1;   // tabu lists: live tour edges per sweep
+        const int slot_cur = TABU ? (int)(sweeps % 4) : 0, slot_read = (slot_cur + 2) & 3;   // tabu lists: live tour edges per sweep; the slot of two sweeps ago
         int si = ci, sj = cj;    // FIRST: where the tiles scan starts (the probe moves it on when it finds nothing)
         bool probe_hit = false;
         if constexpr (!BEST) {
@@ -1264,9 +1274,34 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                 auto npred = [&](int v) { int p2 = (int)pos[a.iid[v]]; p2 = p2 == 0 ? n - 1 : p2 - 1; return a.gid[(int)order[p2]]; };
                 auto live_v = [&](int sv) { return sv != 0 && !(cur_iter - sv > cur_ten); };
                 auto live = [&](int x, int y) { return live_v(a.tabu[udir_pos(x, y, n)]); };
+                // One more live tour edge of this sweep (the C(|F|, 2) term is cluster-wide: the first workgroup reads the count after
+                // the NEXT exchange).  The add must have been performed before this workgroup publishes its next candidate: a
+                // RETURNING atomic whose result the wave waits for -- the barrier behind the exchange comes after it, the publish
+                // after the barrier.  (This was atomicAdd + __threadfence(): the fence writes this XCD's L2 back and invalidates it,
+                // 1.5 - 2 us per live tour edge and sweep, and stamped edges that a move's unchecked second new edge brings back
+                // while their stamp is live are common -- that fence, not the loads, was most of what the list cost a sweep.)
+                auto count_live_edge = [&]() {
+                    const unsigned long long was = atomicAdd(a.tabu_side + 1 + slot_cur, 1ull);
+                    asm volatile("" ::"v"((unsigned)was));
+                };
 #ifdef TSP_STAMPS
                 const unsigned long long ts0 = wall_clock64();
 #endif
+                if (c == 0 && tid == 64) {
+                    // The C(|F|, 2) term of the sweep TWO back (F = its live tour edges, counted cluster-wide in that sweep's slot):
+                    // every workgroup's adds of that sweep came before the candidate it published for the sweep after it, and that
+                    // exchange is complete.  Read (and zeroed) here, beside the first wave's exchange, where it costs the step
+                    // nothing -- as the first thread's act behind the exchange it was 0.6 us of every sweep on the workgroup the
+                    // cluster waits for.  Four slots in turn: the slot is next added to two sweeps on, by workgroups that have
+                    // seen this workgroup's next candidate, which it publishes behind the barrier this wave is still in front of.
+                    unsigned long long *fp = a.tabu_side + 1 + slot_read;
+                    const long long f = (long long)atomicAdd(fp, 0ull);
+                    if (f) {
+                        tabu_cnt -= f * (f - 1) / 2;
+                        const unsigned long long was = atomicExch(fp, 0ull);
+                        asm volatile("" ::"v"((unsigned)was));
+                    }
+                }
                 const int m = min(tl_m, a.tabu_list_cap);
                 // The entries go round the workgroups 1 .. C - 1, one per thread: the first workgroup, which reads the live-edge count
                 // and (in a chain of iterations) decides the kicks, is the one the cluster waits for in every sweep -- its exchange
@@ -1287,7 +1322,13 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     // computed from (no load at all in most sweeps: +6 us per iteration); the first round trip issued before
                     // the scan (+3 us: every wait for a load in the scan then waits for it too); the first workgroup left out of
                     // the group-pair table (no difference).
-                    const bool mine = k == k0;
+                    const bool mine = k == k0 && !(a.dbg & 128);
+                    if (mine && tl_state == 1) {
+#ifdef TSP_STAMPS
+                        ++tl_n_skip;
+#endif
+                        continue;
+                    }
                     int2 e;
                     int iu, iv;
                     if (mine && tl_have) { e = tl_e; iu = tl_iu; iv = tl_iv; }
@@ -1301,11 +1342,24 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     const int pu = (int)pos[iu], pv = (int)pos[iv];
                     const int su_i = (int)order[pu + 1 == n ? 0 : pu + 1], s2_i = (int)order[pv + 1 == n ? 0 : pv + 1];
                     const int pru_i = (int)order[pu == 0 ? n - 1 : pu - 1], prv_i = (int)order[pv == 0 ? n - 1 : pv - 1];
+                    const unsigned nb0 = ((unsigned)su_i << 16) | (unsigned)s2_i, nb1 = ((unsigned)pru_i << 16) | (unsigned)prv_i;
+                    if (mine && tl_state == 2 && nb0 == tl_nb0 && nb1 == tl_nb1) {
+                        tabu_cnt += tl_cnt;
+                        if (tl_edge) count_live_edge();
+#ifdef TSP_STAMPS
+                        ++tl_n_hit;
+#endif
+                        continue;
+                    }
+#ifdef TSP_STAMPS
+                    ++tl_n_full;
+#endif
                     const int sv = *sp;
                     const int su = a.gid[su_i], s2 = a.gid[s2_i], pru = a.gid[pru_i], prv = a.gid[prv_i];
-                    if (sv == 0) continue;
+                    if (sv == 0) { if (mine) tl_state = 1; continue; }
                     const bool uv = su == v, vu = s2 == u;
                     if (!live_v(sv)) {
+                        if (mine) tl_state = (!uv && !vu) ? 1 : 0;
                         if (!uv && !vu) *sp = 0;
                         else {
                             // expired stamp on the tour edge x -> y: cleared iff the reference's chain reaches it
@@ -1314,7 +1368,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             for (int b = x + 1; b < n && !looked; ++b) looked = b != y && b != px && !live(x, b);
                             for (int q = 0; q < x && !looked; ++q) looked = q != px && q != y && !live(q, x) && !live(q, nsucc(q));
                             if (!looked) looked = y < px && px != nsucc(y) && !live(y, px) && !live(y, nsucc(y)) && !live(px, x);
-                            if (looked) *sp = 0;
+                            if (looked) { *sp = 0; if (mine) tl_state = 1; }
                         }
                         continue;
                     }
@@ -1340,9 +1394,9 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     if (edge) {
                         // live tour edges of this sweep, cluster-wide (the C(|F|, 2) term): complete before this workgroup
                         // publishes its NEXT candidate; the first workgroup reads the count after that exchange
-                        atomicAdd(a.tabu_side + 1 + slot_cur, 1ull);
-                        __threadfence();
+                        count_live_edge();
                     }
+                    if (mine) { tl_state = 2; tl_nb0 = nb0; tl_nb1 = nb1; tl_cnt = add; tl_edge = edge; }
                 }
 #ifdef TSP_STAMPS
                 if (tid == 64 && tour == 0 && c < 256) g_cl_tail[c][8] += wall_clock64() - ts0;
@@ -1354,21 +1408,6 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             if (*s_fail) { failed = true; break; }
             bd = *s_win_d; key = *s_win_k; ipair = *s_win_ip;   // rewritten after the barriers of the move below
             view.L = 0;   // carried out by waves 1 .. 7 before this barrier (an exchange step with a pending reversal)
-        }
-        if constexpr (TABU) {
-            if (c == 0 && tid == 0) {   // every workgroup's adds of the sweep BEFORE came before the candidate it has just published
-                // (three slots in turn: the slot read and zeroed here is next added to two sweeps on, by workgroups that have
-                // seen this one's next candidate -- with two, a fast workgroup's adds of the next sweep could slip in before the read)
-                unsigned long long *fp = a.tabu_side + 1 + slot_prev;
-#ifdef TSP_STAMPS
-                const unsigned long long ta0 = wall_clock64();
-#endif
-                const long long f = (long long)atomicAdd(fp, 0ull);
-                if (f) { tabu_cnt -= f * (f - 1) / 2; atomicExch(fp, 0ull); __threadfence(); }   // zero again before this thread publishes the next candidate
-#ifdef TSP_STAMPS
-                if (tour == 0) g_cl_tail[0][9] += wall_clock64() - ta0;
-#endif
-            }
         }
         CL_T(3);
         const bool found = key != kNoKey && (!BEST || bd < 0);
@@ -1591,6 +1630,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     const bool kicked = *s_win_k != kNoKey;
                     const int kword = kicked ? (int)(-*s_win_d) - 1 : 0, ptaken = kword >> 2;
                     if (kicked) tl_m += kword & 3;
+                    tl_state = 0;   // the next iteration's number and tenure decide anew what is live
                     const int ia = kicked ? (int)(*s_win_ip >> 16) : 0, ib = kicked ? (int)(*s_win_ip & 0xffffu) : 0;
                     const int ka1 = kicked ? key_i(*s_win_k) : 0, kb1 = kicked ? key_j(*s_win_k) : 0;
                     if (kicked) {
@@ -1674,6 +1714,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     }
 
 #ifdef TSP_STAMPS
+    if constexpr (TABU) { if (tour == 0 && tid == 64 && c < 256) { g_cl_tail[c][6] += tl_n_full; g_cl_tail[c][9] += tl_n_hit; g_cl_tail[c][11] += tl_n_skip; } }
     if (tour == 0 && tid == 0 && c < 256) { for (int k = 0; k < 6; ++k) g_cl_prof[c][k] += prof[k]; g_cl_prof[c][6] += prof[8] + prof[10]; g_cl_prof[c][7] += steps - st->steps; }
     if (tour == 0 && tid == 0) { for (int k = 8; k < 12; ++k) atomicAdd(&g_cl_cnt[k - 8], prof[k]); atomicAdd(&g_cl_cnt[4], prof[6]); atomicAdd(&g_cl_cnt[5], prof[7]); }
 #endif
@@ -2199,8 +2240,8 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
             if (tabu) {
                 // the failed launch may have consumed or added to the side words of the tabu-list accounting: back to what
                 // they were after the last launch that completed (zero before the first)
-                if (launches_done > 0) (void)hipMemcpyAsync(tabu->d_tabu_pairs, tabu->d_tabu_pairs + 4, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
-                else (void)hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s);
+                if (launches_done > 0) (void)hipMemcpyAsync(tabu->d_tabu_pairs, tabu->d_tabu_pairs + kTabuSideWords, kTabuSideWords * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s);
+                else (void)hipMemsetAsync(tabu->d_tabu_pairs, 0, kTabuSideWords * sizeof(unsigned long long), s);
             }
             tsp::set_last_error("k_cluster_two_opt: a workgroup of the cluster was not resident (exchange gave up)",
                                 hipErrorLaunchFailure, __FILE__, __LINE__);
@@ -2214,7 +2255,7 @@ int tsp_cluster_run(tsp_dev_tours *t, int mode, int C, int64_t max_steps, double
         if (done) { if (all_done) *all_done = 1; break; }
         if (time_limit_s > 0 && wall_s() - t0 > time_limit_s) { status = TSP_TIME_LIMIT_EXCEEDED; break; }
         // another launch follows: keep the tabu-list side words as they stand after this one (see the give-up path)
-        if (tabu) TSP_HIP_TRY(hipMemcpyAsync(tabu->d_tabu_pairs + 4, tabu->d_tabu_pairs, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+        if (tabu) TSP_HIP_TRY(hipMemcpyAsync(tabu->d_tabu_pairs + kTabuSideWords, tabu->d_tabu_pairs, kTabuSideWords * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
     }
     bool unfinished = status == TSP_TIME_LIMIT_EXCEEDED;
     for (int b = 0; b < B; ++b) unfinished = unfinished || !t->h_state[b].done;

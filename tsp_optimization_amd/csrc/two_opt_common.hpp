@@ -8,6 +8,10 @@ namespace tsp {
 
 using u64 = unsigned long long;
 constexpr u64 kNoKey = ~0ull;
+// runs with a tabu list: the handle's side words = {pairs the run's sweeps skipped as tabu, live tour edges of the sweeps whose number
+// is 0 / 1 / 2 / 3 mod 4 (CLUSTER engine; the GRID engine uses [1], [2] within a launch)}
+constexpr int kTabuSideSlots = 4;
+constexpr int kTabuSideWords = 1 + kTabuSideSlots;
 
 // scan-order key of a pair: lexicographic (i, j) == the reference's loop order (heuristics.c:452-454)
 __device__ __forceinline__ u64 make_key(int i, int j) {

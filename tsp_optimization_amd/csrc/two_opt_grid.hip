@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kApplyThreads) void k_tabu_post_chain(TourState *st
         if (!chain[0]) {
             {   // k_tabu_fix_evals: read-and-zero as returning atomics (see there)
                 long long skipped = (long long)atomicExch(side, 0ull);
-                for (int p = 1; p <= 3; ++p) {
+                for (int p = 1; p <= kTabuSideSlots; ++p) {
                     const long long f = (long long)atomicExch(side + p, 0ull);
                     skipped -= f * (f - 1) / 2;
                 }
@@ -262,10 +262,14 @@ bool exh_run(const tsp_dev_tours *t, int mode, const tsp_dev_tabu *tabu) {
 }
 
 constexpr long long kTabuListMax = 16384;   // more non-zero stamps than this: the dense scan (k_step<TABU>)
+// Entries whose stamp has been cleared stay in the list until it is compacted, and every sweep of a run with a list passes over
+// them (CLUSTER engine: an entry per thread, the cluster waits for the slowest).  The list is compacted once this many entries
+// have been appended since the last time (2 048 until round 4: at tenure 200 three entries in four were dead ones).
+constexpr long long kTabuCompactSlack = 256;
 
 // Before a run with a list: bring the handle's list of non-zero stamps up to date (a scan after the host wrote
 // stamps; a compaction once enough cleared entries have piled up) and say whether the run can work from it.
-int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
+int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable, long long room = 0 /* entries the caller is about to append */) {
     *usable = false;
     // any size and any metric: the alternative reads four stamps per pair (60 us per sweep at n = 299 against 19); tours outside
     // the sorted sweep (metrics without the bound) take the tiled step with the side effects as a launch of their own
@@ -276,7 +280,7 @@ int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
         TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), s));
         hipLaunchKernelGGL(k_tabu_scan, dim3(2048), dim3(256), 0, s, tb->d_stamp, tb->count, t->n, tb->d_list, tb->list_cap, tb->d_list_n);
         readback = true;
-    } else if (tb->list_ub > tb->list_compact_at) {
+    } else if (tb->list_ub + room > tb->list_compact_at) {
         hipLaunchKernelGGL(k_tabu_compact, dim3(1), dim3(1024), 0, s, tb->d_stamp, t->n, tb->d_list, tb->d_list_n);
         readback = true;
     }
@@ -287,7 +291,7 @@ int tabu_list_prepare(tsp_dev_tours *t, tsp_dev_tabu *tb, bool *usable) {
         const long long m = *tb->h_list_n;
         tb->list_valid = m <= tb->list_cap;   // an overflowing scan leaves no list: the next run scans again
         tb->list_ub = m;
-        tb->list_compact_at = m + 2048;
+        tb->list_compact_at = m + std::max(kTabuCompactSlack, room);
     }
     *usable = tb->list_valid && tb->list_ub <= kTabuListMax;
     return TSP_OK;
@@ -462,7 +466,7 @@ int tsp_grid_run(tsp_dev_tours *t, int mode, tsp_dev_tabu *tabu, int iter, int t
         if (rc) return rc;
         t->tabu_list_run = usable && TSP_SW(t->inst, TABU_DENSE, 0) == 0;
         tabu->last_run_list = t->tabu_list_run;
-        if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+        if (t->tabu_list_run) TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, kTabuSideWords * sizeof(unsigned long long), s));
     }
     const int64_t batch = 64;
     // launches between two looks at `done`: short descents (a kicked local optimum, a small instance) should not
@@ -570,7 +574,7 @@ int tsp_tabu_run(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, dou
         if (rc) return rc;
         if (usable) {
             hipStream_t s = t->inst->ctx->stream;
-            TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+            TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, kTabuSideWords * sizeof(unsigned long long), s));
             int fell = 0;
             const int status = tsp_cluster_run(t, TSP_2OPT_BEST, tsp_cluster_size(t, TSP_2OPT_BEST), -1, time_limit_s, all_done, &fell,
                                                tabu, iter, tenure);
@@ -808,7 +812,7 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     t->cl_tabu_plan = true;
     struct PlanGuard { tsp_dev_tours *t; ~PlanGuard() { t->cl_tabu_plan = false; } } plan_guard{t};
     bool usable = false;
-    int rc = tabu_list_prepare(t, tabu, &usable);
+    int rc = tabu_list_prepare(t, tabu, &usable, 2ll * count);   // (compacts now if the chain's entries would not fit before the next compaction)
     if (rc) return rc;
     if (!usable || tabu->list_ub + 2ll * count > std::min<long long>(kTabuListMax, tabu->list_cap) || tabu->list_ub + 2ll * count > tabu->list_compact_at)
         return TSP_OK;
@@ -837,7 +841,7 @@ int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, in
     TSP_HIP_TRY(hipMemcpyAsync(t->d_chain, t->h_chain, chain_ints * sizeof(int), hipMemcpyHostToDevice, s));
     rc = tsp_grid_rearm(t, TSP_2OPT_BEST);
     if (rc) return rc;
-    TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, 4 * sizeof(unsigned long long), s));
+    TSP_HIP_TRY(hipMemsetAsync(tabu->d_tabu_pairs, 0, kTabuSideWords * sizeof(unsigned long long), s));
     if (in_kernel) {
         // The iterations run INSIDE the CLUSTER launch (k_cluster_two_opt, TABU variant, chain_n > 0): between two descents the
         // kernel itself keeps the incumbent, decides the kick's first trial and carries it out on the replicas -- what
@@ -1339,13 +1343,13 @@ int tsp_dev_tabu_create(tsp_dev_inst *inst, tsp_dev_tabu **out) {
     tb->list_cap = (int)std::max<long long>(16, std::min<long long>(tb->count, 1ll << 18));
     TSP_HIP_TRY(hipMalloc(&tb->d_list, sizeof(int2) * (size_t)tb->list_cap));
     TSP_HIP_TRY(hipMalloc(&tb->d_list_n, sizeof(int)));
-    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, 8 * sizeof(unsigned long long)));   // 4 side words + their snapshot (CLUSTER engine, multi-launch runs)
+    TSP_HIP_TRY(hipMalloc(&tb->d_tabu_pairs, 2 * kTabuSideWords * sizeof(unsigned long long)));   // the side words + their snapshot (CLUSTER engine, multi-launch runs)
     TSP_HIP_TRY(hipHostMalloc(&tb->h_list_n, sizeof(int)));
     TSP_HIP_TRY(hipMemsetAsync(tb->d_list_n, 0, sizeof(int), inst->ctx->stream));
-    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, 8 * sizeof(unsigned long long), inst->ctx->stream));
+    TSP_HIP_TRY(hipMemsetAsync(tb->d_tabu_pairs, 0, 2 * kTabuSideWords * sizeof(unsigned long long), inst->ctx->stream));
     TSP_HIP_TRY(hipStreamSynchronize(inst->ctx->stream));
     tb->list_valid = true;   // no stamp is set: the empty list is complete
-    tb->list_ub = 0; tb->list_compact_at = 2048;
+    tb->list_ub = 0; tb->list_compact_at = kTabuCompactSlack;
     guard.tb = nullptr;
     *out = tb;
     return TSP_OK;

@@ -86,14 +86,14 @@ __global__ __launch_bounds__(1024) void k_tabu_compact(const int *__restrict__ s
 }
 
 // after a run: evals counted every non-adjacent pair of every sweep; take the skipped ones off (tabusearch.c:150)
-// (side[1 .. 3]: live tour edges of a sweep whose C(|F|, 2) term the CLUSTER engine had not taken off yet -- it does so one
-// sweep later, so the last sweep's is left; the GRID engine leaves them at zero)
+// (side[1 .. 4]: live tour edges of a sweep whose C(|F|, 2) term the CLUSTER engine had not taken off yet -- it does so two
+// sweeps later, so the last two sweeps' are left; the GRID engine leaves them at zero)
 __global__ void k_tabu_fix_evals(TourState *st, unsigned long long *side) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         // read-and-zero as one returning atomic each: as plain code the compiler loads the four words with one scalar load
         // and issues the zeroing vector stores before that load has returned (seen in the ISA: the stores won the race)
         long long skipped = (long long)atomicExch(side, 0ull);
-        for (int p = 1; p <= 3; ++p) {
+        for (int p = 1; p <= kTabuSideSlots; ++p) {
             const long long f = (long long)atomicExch(side + p, 0ull);
             skipped -= f * (f - 1) / 2;
         }
