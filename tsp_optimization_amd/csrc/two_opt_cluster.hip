@@ -512,6 +512,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
     // the iteration of tabu() this launch is at (its number and tenure decide what is tabu): a launch that carries a chain of
     // iterations goes on where the launch before it stopped (chain[1])
     int cur_iter = a.iter, cur_ten = a.tenure, ck = 0, kpp = 0;   // kpp: the pair the next kick trial takes
+    int4 nx_pair = make_int4(0, 0, 0, 0);   // ... fetched ahead ({a, b, a and b inside the replica}: asked for when the kick before it is through)
+    int nx_pp = -1;
     double inc_best = 0.0;
     if constexpr (TABU) {
         if (a.chain_n > 0) {
@@ -519,6 +521,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
             cur_iter = a.iter + ck; cur_ten = a.chain_par[ck];
             inc_best = *reinterpret_cast<const double *>(a.chain + 2);
             kpp = a.chain_pairs > 0 ? *a.chain_pp : ck;
+            if (kpp < (a.chain_pairs > 0 ? a.chain_pairs : a.chain_n)) { nx_pair = reinterpret_cast<const int4 *>(a.chain_ab)[kpp]; nx_pp = kpp; }
         }
     }
 
@@ -1557,8 +1560,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                             __syncthreads();
                         } else
                         for (int pp = kpp;; ++pp) {   // the trials of this iteration's kick, in the order tabu() draws them
-                            const int ka = a.chain_ab[4 * pp], kb = a.chain_ab[4 * pp + 1];
-                            const int ia = a.chain_ab[4 * pp + 2], ib = a.chain_ab[4 * pp + 3];   // the same two nodes inside the replica
+                            const int4 pr = pp == nx_pp ? nx_pair : reinterpret_cast<const int4 *>(a.chain_ab)[pp];
+                            const int ka = pr.x, kb = pr.y, ia = pr.z, ib = pr.w;   // (ia, ib: the same two nodes inside the replica)
                             if (tid == 0) {
                                 const int pa = (int)pos[ia], pb = (int)pos[ib];
                                 s_kick[3] = a.gid[(int)order[pa + 1 == n ? 0 : pa + 1]]; s_kick[4] = a.gid[(int)order[pb + 1 == n ? 0 : pb + 1]];
@@ -1615,7 +1618,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         // -- nobody has to look
                         // anything up before the swaps or before the next sweep's pass over the list
                         ClCand kc{0.0, kNoKey, 0u};
-                        if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)(s_kick[5] + 4 * s_kick[6]); kc.key = make_key(s_kick[3], s_kick[4]); kc.ipair = ((unsigned)a.chain_ab[4 * s_kick[6] + 2] << 16) | (unsigned)a.chain_ab[4 * s_kick[6] + 3]; }
+                        if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)(s_kick[5] + 4 * s_kick[6]); kc.key = make_key(s_kick[3], s_kick[4]); const int4 pr = s_kick[6] == nx_pp ? nx_pair : reinterpret_cast<const int4 *>(a.chain_ab)[s_kick[6]]; kc.ipair = ((unsigned)pr.z << 16) | (unsigned)pr.w; }
                         __threadfence();   // release: this XCD's cleared stamps (and the first workgroup's list entries) are in memory
                         CL_TT(2);
                         bool okx = true;
@@ -1636,11 +1639,14 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     if (kicked) {
                         const int pa = (int)pos[ia], pb = (int)pos[ib];
                         if (tid == 0) {   // :306-309
-                            a.tabu[udir_pos(a.chain_ab[4 * ptaken], ka1, n)] = cur_iter; a.tabu[udir_pos(a.chain_ab[4 * ptaken + 1], kb1, n)] = cur_iter;
-                            // ... and out of this XCD's L2 at once: with tenure 0 the stamp expires in the very iteration that
-                            // follows, another XCD's workgroup clears it (a dirty 0 there), and this copy must not be the one that
-                            // reaches memory last (found by the randomised chains of tools/stress_parity.py)
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            const int4 pr = ptaken == nx_pp ? nx_pair : reinterpret_cast<const int4 *>(a.chain_ab)[ptaken];
+                            a.tabu[udir_pos(pr.x, ka1, n)] = cur_iter; a.tabu[udir_pos(pr.y, kb1, n)] = cur_iter;
+                            // These copies stay dirty in this XCD's L2 until the next boundary's release.  That is too late in one case:
+                            // the NEXT iteration's tenure is 0 -- the stamp expires at once, another XCD's workgroup clears it during that
+                            // iteration (a dirty 0 there), and whichever copy reaches memory last wins (found by the randomised chains
+                            // of tools/stress_parity.py).  Then, and only then, they are written back now (the fence writes the whole
+                            // L2 back: 4 us; the reference's tenures start at 2 % of n).
+                            if (ck + 1 < a.chain_n && a.chain_par[ck + 1] == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                         }
                         if constexpr (INT) {   // the running cost (exact: integer terms)
                             const int a1i = (int)order[pa + 1 == n ? 0 : pa + 1], b1i = (int)order[pb + 1 == n ? 0 : pb + 1];
@@ -1674,6 +1680,7 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     ck += 1;
                     if ((a.dbg & 2048) && c == 1 && ck >= 2) return;   // test hook: a workgroup stops answering in the middle of a chain
                     kpp = a.chain_pairs > 0 ? ptaken + 1 : ck;
+                    if (kicked && kpp < npairs) { nx_pair = reinterpret_cast<const int4 *>(a.chain_ab)[kpp]; nx_pp = kpp; }   // used eleven sweeps on
                     if (kicked && ck < a.chain_n) {   // the next iteration's alg_2opt_tabu, on the kicked tour
                         done = 0;
                         cur_iter = a.iter + ck; cur_ten = a.chain_par[ck];
