@@ -1622,12 +1622,12 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                         // anything up before the swaps or before the next sweep's pass over the list
                         ClCand kc{0.0, kNoKey, 0u};
                         if (c == 0 && s_kick[0]) { kc.d = -1.0 - (double)(s_kick[5] + 4 * s_kick[6]); kc.key = make_key(s_kick[3], s_kick[4]); const int4 pr = s_kick[6] == nx_pp ? nx_pair : reinterpret_cast<const int4 *>(a.chain_ab)[s_kick[6]]; kc.ipair = ((unsigned)pr.z << 16) | (unsigned)pr.w; }
-                        __threadfence();   // release: this XCD's cleared stamps (and the first workgroup's list entries) are in memory
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // this XCD's cleared stamps (and the first workgroup's list entries) are in memory
                         CL_TT(2);
                         bool okx = true;
                         if (C > 1) okx = cl_exchange<BEST, SORTED, kSmallD>(area, C, c, ++xep, kc, a.err, a.spin_limit, a.spin_ticks, a.copies, mycopy);
                         CL_TT(3);
-                        __threadfence();   // acquire: nothing this CU or its L2 holds of the stamps / the list outlives the boundary
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // nothing this CU or its L2 holds of the stamps / the list outlives the boundary
                         CL_TT(4);
                         if (lane == 0) { *s_win_d = kc.d; *s_win_k = kc.key; *s_win_ip = kc.ipair; *s_fail = okx ? 0 : 1; }
                     }
