@@ -1540,7 +1540,8 @@ __global__ __launch_bounds__(kClThreads) void k_cluster_two_opt(const ClusterArg
                     // written back at once when the next iteration's tenure is 0 (see there).
                     // Measured and not kept: the first trial's inputs (successors, the four stamps, the list look-up) read ahead by an
                     // idle wave of the first workgroup during every sweep's exchange -- its decision 4.8 -> 1.7 us, the iteration
-                    // unchanged (111.2 us): the boundary's exchange, behind 256 simultaneous L2 write-backs, is what the tail waits for.
+                    // unchanged (111.2 us with two-sided fences at the boundary, 108.4 with the one-sided ones): the boundary's exchange,
+                    // behind 256 simultaneous L2 write-backs, is what the tail waits for.
                     const int npairs = a.chain_pairs > 0 ? a.chain_pairs : a.chain_n;
                     int *res = a.chain + 4 + 10 * ck;
                     int *s_kick = reinterpret_cast<int *>(s_chunk);   // {accepted, have0, have1, a1, b1, entries appended, pair taken}: the cost's chunks are through
