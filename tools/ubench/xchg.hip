@@ -59,6 +59,79 @@ __global__ __launch_bounds__(64) void k_xchg(u64 *area, int stride, int rounds, 
     if (acc == 12345.678) area[600] = 1;
 }
 
+
+// The same round with the sweep PIPELINED: the loads of the next pass are in flight while the tags of this one are checked
+// (a pass is one round trip to memory: the last arriver's tags are seen half a pass earlier on average, for twice the polling traffic).
+template <int SCOPE, int NG>
+__global__ __launch_bounds__(64) void k_xchg_pipe(u64 *area, int rounds, int *err, int work, int copies, int cstride) {
+    const int G = gridDim.x, c = blockIdx.x, lane = threadIdx.x;
+    double acc = lane;
+    unsigned myx;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(myx));
+    const int mycopy = copies == 8 ? (int)(myx & 7) : c % copies;
+    for (int r = 1; r <= rounds; ++r) {
+        for (int w = 0; w < work; ++w) acc = fma(acc, 1.0000001, 0.5);
+        u64 *par = area + (size_t)(r & 1) * 256 * NG;
+        const u64 tag = (u64)r << 32;
+        if (lane < copies) {
+#pragma unroll
+            for (int w = 0; w < NG; ++w) __hip_atomic_store(par + (size_t)lane * cstride + w * 256 + c, tag | (unsigned)c | (acc < 0 ? 1u : 0u), __ATOMIC_RELAXED, SCOPE);
+        }
+        const u64 *mine = par + (size_t)mycopy * cstride;
+        u64 gA[4][NG], gB[4][NG];
+        auto issue = [&](u64 (&g)[4][NG]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 64 < G) {
+#pragma unroll
+                    for (int w = 0; w < NG; ++w) g[q][w] = __hip_atomic_load(mine + w * 256 + q * 64 + lane, __ATOMIC_RELAXED, SCOPE);
+                }
+        };
+        auto good = [&](u64 (&g)[4][NG]) {
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 64 < G && q * 64 + lane < G) {
+#pragma unroll
+                    for (int w = 0; w < NG; ++w) ok = ok && (g[q][w] >> 32) == (u64)r;
+                }
+            return __all(ok);
+        };
+        unsigned spins = 0;
+        issue(gA);
+        for (;;) {
+            issue(gB);
+            if (good(gA)) break;
+            issue(gA);
+            if (good(gB)) break;
+            if (++spins > (1u << 17)) { if (lane == 0) *err = 1; return; }
+        }
+    }
+    if (acc == 12345.678) area[600] = 1;
+}
+
+template <int NG>
+void run_pipe(int work, int copies) {
+    u64 *area; int *err;
+    const int cstride = 512 * NG;
+    const size_t bytes = 8 * (size_t)(64 * cstride + 4096); hipMalloc(&area, bytes); hipMemset(area, 0, bytes);
+    hipMalloc(&err, 4); hipMemset(err, 0, 4);
+    const int rounds = 4000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipMemset(area, 0, bytes);
+        hipEventRecord(e0);
+        k_xchg_pipe<__HIP_MEMORY_SCOPE_AGENT, NG><<<256, 64>>>(area, rounds, err, work, copies, cstride);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    int h_err = 0; hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost);
+    printf("pipelined  NG %d G 256 work %4d copies %2d: %.3f us per round%s\n", NG, work, copies, 1e3 * best / rounds, h_err ? "  GAVE UP" : "");
+    hipFree(area); hipFree(err);
+}
+
 // The transport the round-3 verdict asked to price: per-XCD replicas of {one 64-bit atomicMin word, one arrival counter}.  A
 // workgroup adds its candidate to ALL eight replicas (lanes 0..7: atomicMin, lanes 8..15: atomicAdd on the counters), then polls
 // ONE counter word (its XCD's) until the round's G arrivals are in, then reads ONE min word.  Three slots in turn; workgroup 0
@@ -193,6 +266,12 @@ void run(const char *name, int stride, int work, int copies = 1, int cstride = 5
 int main() {
     run<__HIP_MEMORY_SCOPE_AGENT, 1>("flat sc1", 1, 0, 8, 512, 1, 0);   // the product's transport: tagged granules, a copy of the area per XCD
     run<__HIP_MEMORY_SCOPE_AGENT, 1>("flat sc1", 1, 0, 1, 512, 1, 0);
+    // three granules per candidate (the sorted best-improvement scan's), with and without work between the rounds, plain against pipelined sweep
+    for (int work : {0, 1500}) {
+        run<__HIP_MEMORY_SCOPE_AGENT, 3>("flat sc1", 1, work, 8, 1536, 1, 0);
+        run<__HIP_MEMORY_SCOPE_AGENT, 3>("flat sc1", 1, work, 8, 1536, 0, 0);
+        run_pipe<3>(work, 8);
+    }
     run_xmin();
     return 0;
 }
