@@ -1096,7 +1096,7 @@ int tsp_dev_tours_create(tsp_dev_inst *inst, int B, tsp_dev_tours **out) {
             t->exh_gens = 0;
             int pc[4] = {0, 0, 0, 0};
             bool on = B == 1 && waves >= 2 && waves <= 4;
-            if (waves == 4) { pc[0] = 53; pc[1] = 26; pc[2] = 13; pc[3] = 8; }
+            if (waves == 4) { pc[0] = 52; pc[1] = 28; pc[2] = 13; pc[3] = 7; }   // (tools/exh_shares.sh: 44.7 us per sweep against 45.7 with 53 / 26 / 13 / 8)
             if (waves == 3) { pc[0] = 56; pc[1] = 29; pc[2] = 15; }
             if (waves == 2) { pc[0] = 62; pc[1] = 38; }
             const char *e = getenv("TSP_EXH_SHARES");
