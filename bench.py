@@ -800,7 +800,7 @@ def main():
         tabu_rate(None, 60)
         single = tabu_rate(1, iters)
         res["tabu_iterations_on_resident_state"] = dict(
-            chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123: chains of up to 64 iterations "
+            chained, driver="tsp_host_tabu(inst, step policy, cap on the iterations) of libtsp_host.so, seed 123: chains of up to 128 iterations "
                             "INSIDE one CLUSTER launch (incumbent, the kick's trials, the kick and the next descent in the kernel; "
                             "tsp_dev_tours_tabu_iterations_ex)",
             queued_launches=dict(queued, what="TSP_TABU_INKERNEL=0: the launches of a chain queued back to back, one small kernel between two"),

@@ -217,7 +217,7 @@ int tsp_dev_tours_tabu_kick(tsp_dev_tours *t, tsp_dev_tabu *tabu, int a, int b, 
  * no kick is made (:255-258).  obj / improved / accepted may be NULL. */
 int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int tenure, double time_limit_s, int a, int b,
                                  double *best_obj, double *obj, int *improved, int *accepted);
-/* `count` (<= 64) iterations of tabu() in ONE wait for the device: iteration iter0 + k runs alg_2opt_tabu with tenure[k], updates
+/* `count` (<= 128) iterations of tabu() in ONE wait for the device: iteration iter0 + k runs alg_2opt_tabu with tenure[k], updates
  * the incumbent and makes the FIRST trial of its kick with the host-drawn nodes ab[2k], ab[2k + 1] (what
  * tsp_dev_tours_tabu_iteration does for one iteration) -- the iterations run inside one launch of the CLUSTER engine (or, TSP_TABU_INKERNEL=0, as launches queued back
  * to back) and a word on the device stops the chain as soon as an iteration cannot be completed there.  *completed = iterations that ran up to their kick's trial; obj[k] /
@@ -230,7 +230,7 @@ int tsp_dev_tours_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter,
 int tsp_dev_tours_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, const int *ab,
                                   double time_limit_s, double *best_obj, double *obj, int *improved, int *completed, int *last_accepted);
 /* The same with the kick's FURTHER trials on the device too (src/tabusearch.c:262-287 draws pairs until one is accepted): ab holds
- * `pairs` (count <= pairs <= 128) node pairs in the order tabu() would draw them, and the iterations take them in that order --
+ * `pairs` (count <= pairs <= 256) node pairs in the order tabu() would draw them, and the iterations take them in that order --
  * iteration iter0 + k starts with the pair after the last one iteration iter0 + k - 1 took, and a rejected trial is followed by
  * the next pair, all inside the launch (the CLUSTER engine's tabu variant runs the iterations itself: incumbent, trials, kick
  * and the next descent on the replicas).  trials[k] = pairs iteration k took (0 when the earlier iterations had used them all up: no trial was made); the caller has consumed

@@ -785,7 +785,7 @@ int tsp_grid_tabu_iteration(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter, int 
 // engine, a long list): nothing was touched.
 int tsp_grid_tabu_iterations(tsp_dev_tours *t, tsp_dev_tabu *tabu, int iter0, int count, const int *tenure, int pairs, const int *ab, double time_limit_s,
                              double *best_obj, double *obj, int *improved, int *trials, int *completed, int *last_accepted) {
-    constexpr int kMaxChain = 64, kMaxPairs = 128;
+    constexpr int kMaxChain = 128, kMaxPairs = 256;
     if (!t || !tabu || t->B != 1 || tabu->inst != t->inst || !best_obj || !tenure || !ab || !completed || count < 1) return TSP_DEV_E_ARG;
     *completed = 0;
     if (last_accepted) *last_accepted = 0;

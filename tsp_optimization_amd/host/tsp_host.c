@@ -34,7 +34,7 @@
  * three draws); where it does not hold, the fallback is a window of values handed back (host_random_unget) that every draw of
  * this file -- URAND(), rand_choice(), the skipped draws of a shard -- serves first: the sequence consumed is still the
  * reference's, only a reseed by the caller in between would not clear it. */
-#define AHEAD_CAP 512
+#define AHEAD_CAP 1024
 static long g_ahead[AHEAD_CAP];
 static int g_ahead_n = 0;   /* values waiting, oldest first (fallback only) */
 
@@ -101,7 +101,7 @@ static void host_random_rewind(const random_mark *m, int marked, const long *raw
 #define URAND() (((double)host_random()) / RAND_MAX)   /* include/utility.h:36 (the fallback's window first) */
 
 #define GRASP_ITER_TIME_LIM 120 /* src/heuristics.c:11 */
-#define TABU_CHAIN 64           /* most iterations of tabu() queued per wait for the device */
+#define TABU_CHAIN 128          /* most iterations of tabu() per wait for the device */
 #define MULTISTART_BATCH 256    /* GRASP starts constructed per device call in HEU_Grasp_iter */
 
 /* ---- device context and instance cache -------------------------------------------------------- */
@@ -622,7 +622,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
     if (lo == hi) hi += 2; else if (hi < lo) { int tt = lo; lo = hi; hi = tt; }
     int tenure = lo, rising = 0;
     const char *chain_env = getenv("TSP_TABU_CHAIN");
-    const int chain_max = chain_env && *chain_env ? (atoi(chain_env) < 1 ? 1 : (atoi(chain_env) > 64 ? 64 : atoi(chain_env))) : TABU_CHAIN;
+    const int chain_max = chain_env && *chain_env ? (atoi(chain_env) < 1 ? 1 : (atoi(chain_env) > TABU_CHAIN ? TABU_CHAIN : atoi(chain_env))) : TABU_CHAIN;
     int iter = 1;
     /* a chain stops at the first rejected kick, and the launches queued behind that point are wasted (no-ops, ~10 us each): the
      * chain is made one and a half times as long as the chains have lately run (rand10000, step policy: one first trial in
@@ -647,9 +647,9 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
         if (policy == 2)
             for (int k = 0; k < K - 1; k++)
                 if (iter + k == 1 || (iter + k) % 100 == 0) { K = k + 1; break; }
-        int tenures[64], ab[256], improved[64] = {0}, trials[64];
-        long raw[256];
-        double objs[64];
+        int tenures[TABU_CHAIN], ab[4 * TABU_CHAIN], improved[TABU_CHAIN] = {0}, trials[TABU_CHAIN];
+        long raw[4 * TABU_CHAIN];
+        double objs[TABU_CHAIN];
         {
             int ten = tenure, ris = rising;
             for (int k = 0; k < K; k++) {
@@ -661,7 +661,7 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
          * would make them: K first trials and a reserve for the further ones (one first trial in twelve is rejected at n = 10 000,
          * one in six at n = 299).  With the iterations inside the launch the device takes the pairs in order, further trials
          * included, and reports how many each iteration took; what it did not take goes back to the front of the window. */
-        const int P = in_kernel ? (K + K / 3 + 4 > 128 ? 128 : K + K / 3 + 4) : K;
+        const int P = in_kernel ? (K + K / 3 + 4 > 2 * TABU_CHAIN ? 2 * TABU_CHAIN : K + K / 3 + 4) : K;
         random_mark mark;
         const int marked = host_random_mark(&mark);
         for (int k = 0; k < 2 * P; k++) { raw[k] = host_random(); ab[k] = (int)((((double)raw[k]) / RAND_MAX) * n); }
