@@ -641,7 +641,8 @@ int tsp_host_tabu(instance *inst, int policy, long long max_iterations) {
          * the iterations, and -- random policy -- at an iteration whose policy step draws (:69-72: that draw comes after the
          * iteration's kick draws, so the iteration is the chain's last).  Step and linear policies draw nothing: the tenure of
          * every iteration of the chain is known now. */
-        int K = chain_env && *chain_env ? chain_max : (int)(1.5 * mean_run + 2.0);
+        /* (inside the launch a rejected trial does not end the chain: the longest chain from the start) */
+        int K = (chain_env && *chain_env) || in_kernel ? chain_max : (int)(1.5 * mean_run + 2.0);
         if (K > chain_max) K = chain_max;
         if (max_iterations >= 0 && K > max_iterations - iter + 1) K = (int)(max_iterations - iter + 1);
         if (policy == 2)
